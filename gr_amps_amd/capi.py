@@ -1,0 +1,271 @@
+"""ctypes binding of the C ABI (include/amps_recc.h) -- the only way Python reaches the HIP path.
+
+There is deliberately no pure-Python / torch / numpy implementation of any entry point here: if
+libamps_recc.so is missing or no HIP device is usable, calls raise (the library itself returns
+-ENODEV from amps_recc_create).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libamps_recc.so")
+
+CAPTURE = 3374
+MAX_WORK_ITEMS = 61439
+MEM_HOST, MEM_DEVICE = 0, 1
+FLAG_TIME_KERNELS = 1
+
+MSG_CLASSES = ("invalid_word_a", "e_zero", "page_response", "registration", "origination", "bad_nawc", "unknown")
+
+# mirrors amps_recc_burst_t; checked against amps_recc_burst_size() at load
+BURST_DTYPE = np.dtype([
+    ("channel", "<u4"), ("flags", "<u4"), ("position", "<u8"),
+    ("dcc", "u1", (7,)), ("dcc_bad", "u1"),
+    ("manch_bad", "<u2", (7,)), ("valid", "u1", (7,)), ("first_valid_rep", "u1", (7,)),
+    ("word_raw", "u1", (7, 48)), ("word_dec", "u1", (7, 36)),
+    ("a_F", "u1"), ("a_NAWC", "u1"), ("a_T", "u1"), ("a_S", "u1"), ("a_E", "u1"), ("a_ER", "u1"),
+    ("a_SCM", "u1"), ("_pad0", "u1"), ("a_MIN1", "<u4"),
+    ("b_F", "u1"), ("b_NAWC", "u1"), ("b_MSG_TYPE", "u1"), ("b_ORDQ", "u1"), ("b_ORDER", "u1"),
+    ("b_LT", "u1"), ("b_EP", "u1"), ("b_SCM4", "u1"), ("b_MPCI", "u1"), ("b_SDCC1", "u1"),
+    ("b_SDCC2", "u1"), ("_pad1", "u1"), ("b_MIN2", "<u2"), ("_pad2", "<u2"),
+    ("esn", "<u4"), ("has_esn", "u1"), ("msg_class", "u1"), ("n_called_words", "u1"), ("_pad3", "u1"),
+    ("min", "S12"), ("dialed", "S36"), ("_pad4", "<u4"),
+], align=False)
+
+
+class Cfg(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("n_channels", C.c_uint32), ("samples_per_symbol", C.c_uint32),
+        ("max_samples_per_push", C.c_uint32), ("max_bursts", C.c_uint32), ("device", C.c_int32),
+        ("flags", C.c_uint32), ("wideband_channels", C.c_uint32), ("wideband_decim", C.c_uint32),
+        ("wideband_taps_per_branch", C.c_uint32), ("wideband_first_channel", C.c_uint32),
+        ("_reserved", C.c_uint32), ("stream", C.c_void_p),
+    ]
+
+
+class Timing(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("launches_front", C.c_uint32), ("ms_front", C.c_double),
+        ("ms_resolve", C.c_double), ("ms_decode", C.c_double), ("ms_carry", C.c_double),
+        ("ms_symbols", C.c_double), ("samples_front", C.c_uint64),
+    ]
+
+
+class Reply(C.Structure):
+    _fields_ = [
+        ("has_focc", C.c_uint8), ("focc_stream", C.c_int32), ("focc_nwords", C.c_int32),
+        ("focc_word1", C.c_uint8 * 28), ("focc_word2", C.c_uint8 * 28),
+        ("has_fvc", C.c_uint8), ("fvc_count", C.c_int32), ("fvc_word1", C.c_uint8 * 28),
+        ("fvc_repeat", C.c_uint64),
+        ("has_mutes", C.c_uint8), ("fvc_mute", C.c_uint8), ("audio_mute", C.c_uint8),
+        ("has_command", C.c_uint8), ("command", C.c_char * 48),
+    ]
+
+
+EXPORTS = (
+    "amps_recc_abi_version", "amps_recc_strerror", "amps_recc_burst_size", "amps_recc_create",
+    "amps_recc_destroy", "amps_recc_reset", "amps_recc_push_symbols", "amps_recc_decode_bursts",
+    "amps_recc_push_iq", "amps_recc_push_wideband", "amps_recc_drain", "amps_recc_debug_demod",
+    "amps_recc_get_timing", "amps_recc_reply_words",
+)
+
+_lib = None
+
+
+class AmpsError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = load().amps_recc_strerror(code).decode() if _lib is not None else "library not loaded"
+        super().__init__(f"{where}: {msg} ({code})")
+
+
+def load():
+    """dlopen the C-ABI library.  Raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not built -- run `python -c 'import __graft_entry__ as g; g.build()'`; "
+                          "there is no CPU fallback for the RECC path")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.amps_recc_abi_version.restype = C.c_int
+    L.amps_recc_strerror.argtypes = [C.c_int]
+    L.amps_recc_strerror.restype = C.c_char_p
+    L.amps_recc_burst_size.restype = C.c_size_t
+    L.amps_recc_create.argtypes = [C.POINTER(vp), C.POINTER(Cfg)]
+    L.amps_recc_destroy.argtypes = [vp]
+    L.amps_recc_destroy.restype = None
+    L.amps_recc_reset.argtypes = [vp]
+    L.amps_recc_push_symbols.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.amps_recc_decode_bursts.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, vp]
+    L.amps_recc_push_iq.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int]
+    L.amps_recc_push_wideband.argtypes = [vp, vp, C.c_size_t, C.c_int]
+    L.amps_recc_drain.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.amps_recc_debug_demod.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, vp, vp]
+    L.amps_recc_get_timing.argtypes = [vp, C.POINTER(Timing), C.c_int]
+    L.amps_recc_reply_words.argtypes = [vp, C.POINTER(Reply)]
+    for name in EXPORTS:
+        if name not in ("amps_recc_strerror", "amps_recc_burst_size", "amps_recc_destroy"):
+            getattr(L, name).restype = C.c_int
+    if L.amps_recc_burst_size() != BURST_DTYPE.itemsize:
+        raise ImportError("amps_recc_burst_t layout mismatch between binding and library")
+    _lib = L
+    return L
+
+
+def _hostptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _as_ptr(x):
+    """numpy array -> (pointer, MEM_HOST, keepalive); torch CUDA tensor -> (pointer, MEM_DEVICE, keepalive)"""
+    if isinstance(x, np.ndarray):
+        return _hostptr(x), MEM_HOST, x
+    if hasattr(x, "data_ptr"):
+        if x.is_cuda:
+            return C.c_void_p(x.data_ptr()), MEM_DEVICE, x
+        a = x.numpy()
+        return _hostptr(a), MEM_HOST, a
+    raise TypeError(type(x))
+
+
+class Recc:
+    """One handle = `n_channels` independent RECC receivers on one MI355X."""
+
+    def __init__(self, n_channels=1, sps=10, max_samples=0, max_bursts=1024, device=-1, time_kernels=False,
+                 stream=None, wideband=None):
+        L = load()
+        cfg = Cfg()
+        cfg.struct_size = C.sizeof(Cfg)
+        cfg.n_channels = n_channels
+        cfg.samples_per_symbol = sps
+        cfg.max_samples_per_push = max_samples
+        cfg.max_bursts = max_bursts
+        cfg.device = device
+        cfg.flags = FLAG_TIME_KERNELS if time_kernels else 0
+        cfg.stream = stream
+        if wideband:
+            cfg.wideband_channels = wideband["channels"]
+            cfg.wideband_decim = wideband["decim"]
+            cfg.wideband_taps_per_branch = wideband.get("taps_per_branch", 8)
+            cfg.wideband_first_channel = wideband.get("first_channel", 0)
+        self.n_channels, self.sps, self.max_bursts, self.max_samples = n_channels, sps, max_bursts, max_samples
+        self._h = C.c_void_p()
+        rc = L.amps_recc_create(C.byref(self._h), C.byref(cfg))
+        if rc != 0:
+            self._h = None
+            raise AmpsError(rc, "amps_recc_create")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().amps_recc_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def reset(self):
+        rc = load().amps_recc_reset(self._h)
+        if rc:
+            raise AmpsError(rc, "amps_recc_reset")
+
+    # ---- seam (i): recc::work ----
+    def push_symbols(self, syms, n=None):
+        """syms: uint8 [C][ld] (numpy or torch cuda). One work() call per channel with noutput_items=n.
+        Returns (bursts uint8 [k][3374], channels uint32 [k])."""
+        if isinstance(syms, np.ndarray):
+            syms = np.ascontiguousarray(syms, np.uint8)
+        syms2 = syms.reshape(self.n_channels, -1)
+        ld = syms2.shape[1]
+        n = ld if n is None else n
+        ptr, mem, keep = _as_ptr(syms2)
+        out = np.zeros((self.max_bursts, CAPTURE), np.uint8)
+        ch = np.zeros(self.max_bursts, np.uint32)
+        nout = C.c_size_t(0)
+        rc = load().amps_recc_push_symbols(self._h, ptr, ld, n, mem, _hostptr(out), _hostptr(ch), self.max_bursts, C.byref(nout))
+        if rc:
+            raise AmpsError(rc, "amps_recc_push_symbols")
+        return out[:nout.value].copy(), ch[:nout.value].copy()
+
+    def decode_bursts(self, bursts, channels=None):
+        if isinstance(bursts, np.ndarray):
+            bursts = np.ascontiguousarray(bursts, np.uint8).reshape(-1, CAPTURE)
+        nb = bursts.shape[0]
+        out = np.zeros(nb, BURST_DTYPE)
+        if nb == 0:
+            return out
+        ptr, mem, keep = _as_ptr(bursts)
+        chp = None
+        if channels is not None:
+            channels = np.ascontiguousarray(channels, np.uint32)
+            chp = _hostptr(channels)
+        rc = load().amps_recc_decode_bursts(self._h, ptr, nb, mem, chp, _hostptr(out))
+        if rc:
+            raise AmpsError(rc, "amps_recc_decode_bursts")
+        return out
+
+    # ---- seam (ii): fused IQ ----
+    def push_iq(self, iq, nsamp=None):
+        """iq: complex64 [C][ld] numpy array, or torch cuda tensor (complex64 [C][ld] or float32 [C][ld][2])."""
+        if isinstance(iq, np.ndarray):
+            iq = np.ascontiguousarray(iq, np.complex64).reshape(self.n_channels, -1)
+            ld = iq.shape[1]
+        else:
+            ld = iq.shape[1]
+        nsamp = ld if nsamp is None else nsamp
+        ptr, mem, keep = _as_ptr(iq)
+        rc = load().amps_recc_push_iq(self._h, ptr, ld, nsamp, mem)
+        if rc:
+            raise AmpsError(rc, "amps_recc_push_iq")
+
+    def push_wideband(self, iq):
+        if isinstance(iq, np.ndarray):
+            iq = np.ascontiguousarray(iq, np.complex64).reshape(-1)
+        n = iq.shape[0]
+        ptr, mem, keep = _as_ptr(iq)
+        rc = load().amps_recc_push_wideband(self._h, ptr, n, mem)
+        if rc:
+            raise AmpsError(rc, "amps_recc_push_wideband")
+
+    def drain(self, cap=None):
+        cap = cap or self.max_bursts
+        out = np.zeros(cap, BURST_DTYPE)
+        nout = C.c_size_t(0)
+        rc = load().amps_recc_drain(self._h, _hostptr(out), cap, C.byref(nout))
+        if rc:
+            raise AmpsError(rc, "amps_recc_drain")
+        return out[:nout.value].copy()
+
+    def debug_demod(self, iq):
+        iq = np.ascontiguousarray(iq, np.complex64).reshape(-1)
+        n = iq.size
+        d, s, g = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.uint8)
+        rc = load().amps_recc_debug_demod(self._h, _hostptr(iq), n, MEM_HOST, _hostptr(d), _hostptr(s), _hostptr(g))
+        if rc:
+            raise AmpsError(rc, "amps_recc_debug_demod")
+        p = (n // 64) * 64
+        return d[:p], s[:p], g[:p]
+
+    def timing(self, reset=False):
+        t = Timing()
+        rc = load().amps_recc_get_timing(self._h, C.byref(t), int(reset))
+        if rc:
+            raise AmpsError(rc, "amps_recc_get_timing")
+        return {k: getattr(t, k) for k, _ in Timing._fields_ if k != "struct_size"}
+
+
+def reply_words(rec):
+    rec = np.ascontiguousarray(rec)
+    r = Reply()
+    rc = load().amps_recc_reply_words(_hostptr(rec), C.byref(r))
+    if rc:
+        raise AmpsError(rc, "amps_recc_reply_words")
+    return r

@@ -1,0 +1,651 @@
+// amps_recc.hip -- C ABI implementation (include/amps_recc.h) over the gfx950 kernels.
+// Host code only orchestrates: buffers, stream, launches, result copy-out.  There is no CPU
+// compute path: every entry point that produces data launches HIP kernels, and handle creation
+// fails with -ENODEV when no HIP device is usable.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "amps_recc.h"
+#include "amps_recc_numerics.h"
+#include "recc_front.hip.h"
+#include "recc_resolve.hip.h"
+#include "recc_symbols.hip.h"
+#include "recc_channelizer.hip.h"
+
+static_assert(sizeof(amps_recc_burst_t) == AMPS_RECC_BURST_BYTES, "record layout is part of the ABI");
+static_assert(sizeof(amps_recc_burst_t) % 8 == 0, "records are copied as dwords");
+
+namespace {
+
+using namespace amps;
+
+#define HIP_TRY(expr)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            std::fprintf(stderr, "amps_recc: %s failed: %s\n", #expr, hipGetErrorString(e_)); \
+            return e_ == hipErrorOutOfMemory ? -ENOMEM : -EIO;                          \
+        }                                                                               \
+    } while (0)
+
+enum { T_FRONT = 0, T_RESOLVE, T_DECODE, T_CARRY, T_SYMBOLS, T_CHANNELIZER, T_COUNT };
+
+struct TimedSpan { hipEvent_t a, b; int tag; uint64_t samples; };
+
+} // namespace
+
+struct amps_recc {
+    amps_recc_cfg_t cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint32_t C = 0, sps = 0;
+
+    // ---- IQ seam ----
+    float2 *carry[2] = { nullptr, nullptr };
+    int carry_cur = 0;
+    uint64_t n_done = 0;
+    uint32_t r_prev = 0;
+    uint64_t *gring = nullptr;
+    uint32_t ring_words = 0;
+    uint32_t tiles_per_chunk = 0, max_chunks = 0, det_cap = 0;
+    uint64_t *det = nullptr;
+    uint32_t *detcount = nullptr;
+    uint64_t *next_allowed = nullptr, *pending = nullptr;
+    uint64_t *capq = nullptr;
+    uint32_t *capq_count = nullptr;
+    amps_recc_burst_t *records = nullptr;
+    uint32_t *nrecords = nullptr;
+    uint32_t *status = nullptr;
+    float2 *stage_iq = nullptr;       // device staging for host-resident IQ
+    size_t stage_iq_samples = 0;
+
+    // ---- channelizer seam ----
+    ChannelizerState chz;
+
+    // ---- symbol seam ----
+    uint8_t *symbuf = nullptr;
+    uint32_t *sym_len = nullptr;
+    int32_t *sym_cur = nullptr;
+    uint8_t *sym_stage = nullptr;     // [C][MAX_WORK_ITEMS]
+    uint8_t *bursts_dev = nullptr;    // [max_bursts][3374]
+    uint32_t *burst_chan_dev = nullptr;
+    uint32_t *nbursts_dev = nullptr;
+    amps_recc_burst_t *dec_out_dev = nullptr; // decode_bursts output staging
+    size_t dec_out_cap = 0;
+    uint8_t *dec_in_dev = nullptr;
+    uint32_t *dec_chan_dev = nullptr;
+
+    // ---- timing ----
+    bool timing = false;
+    std::vector<TimedSpan> spans;
+    double ms[T_COUNT] = { 0 };
+    uint32_t launches_front = 0;
+    uint64_t samples_front = 0;
+
+    // ---- debug taps (amps_recc_debug_demod) ----
+    float *dbg_d = nullptr, *dbg_S = nullptr;
+};
+
+namespace {
+
+template <typename T> int dev_alloc(T **p, size_t n)
+{
+    if (n == 0) n = 1;
+    hipError_t e = hipMalloc((void **)p, n * sizeof(T));
+    if (e != hipSuccess) { *p = nullptr; return -ENOMEM; }
+    return 0;
+}
+
+struct SpanGuard {   // records a pair of events around a launch when timing is on
+    amps_recc *h; int tag; uint64_t samples; hipEvent_t a = nullptr, b = nullptr; bool on;
+    SpanGuard(amps_recc *h_, int tag_, uint64_t samples_ = 0) : h(h_), tag(tag_), samples(samples_), on(h_->timing)
+    {
+        if (!on) return;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(a, h->stream);
+    }
+    ~SpanGuard()
+    {
+        if (!on) return;
+        (void)hipEventRecord(b, h->stream);
+        h->spans.push_back({ a, b, tag, samples });
+    }
+};
+
+void collect_spans(amps_recc *h)   // stream must be synchronised
+{
+    for (auto &s : h->spans) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, s.a, s.b) == hipSuccess) {
+            h->ms[s.tag] += t;
+            if (s.tag == T_FRONT || s.tag == T_CHANNELIZER) { h->launches_front++; h->samples_front += s.samples; }
+        }
+        (void)hipEventDestroy(s.a);
+        (void)hipEventDestroy(s.b);
+    }
+    h->spans.clear();
+}
+
+uint32_t next_pow2(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return (uint32_t)p; }
+
+int reset_state(amps_recc *h)
+{
+    hipStream_t s = h->stream;
+    if (h->carry[0]) {
+        HIP_TRY(hipMemsetAsync(h->carry[0], 0, sizeof(float2) * (size_t)h->C * CARRY_CAP, s));
+        HIP_TRY(hipMemsetAsync(h->carry[1], 0, sizeof(float2) * (size_t)h->C * CARRY_CAP, s));
+        HIP_TRY(hipMemsetAsync(h->gring, 0xff, sizeof(uint64_t) * (size_t)h->C * h->ring_words, s));
+        HIP_TRY(hipMemsetAsync(h->detcount, 0, sizeof(uint32_t) * (size_t)h->C * h->max_chunks, s));
+        HIP_TRY(hipMemsetAsync(h->next_allowed, 0, sizeof(uint64_t) * h->C, s));
+        HIP_TRY(hipMemsetAsync(h->pending, 0xff, sizeof(uint64_t) * h->C, s));
+        HIP_TRY(hipMemsetAsync(h->capq_count, 0, sizeof(uint32_t), s));
+    }
+    HIP_TRY(hipMemsetAsync(h->nrecords, 0, sizeof(uint32_t), s));
+    HIP_TRY(hipMemsetAsync(h->status, 0, sizeof(uint32_t), s));
+    HIP_TRY(hipMemsetAsync(h->symbuf, 0, (size_t)h->C * AMPS_RECC_SYMBUF, s));
+    HIP_TRY(hipMemsetAsync(h->sym_len, 0, sizeof(uint32_t) * h->C, s));
+    HIP_TRY(hipMemsetAsync(h->sym_cur, 0xff, sizeof(int32_t) * h->C, s));
+    HIP_TRY(hipMemsetAsync(h->nbursts_dev, 0, sizeof(uint32_t), s));
+    h->carry_cur = 0;
+    h->n_done = 0;
+    h->r_prev = 0;
+    int rc = channelizer_reset(h->chz, s);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+template <int SPS> void launch_front(const FrontArgs &fa, dim3 grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(recc_front_kernel<SPS>, grid, dim3(256), 0, s, fa);
+}
+
+bool sps_supported(uint32_t sps)
+{
+    switch (sps) { case 3: case 4: case 5: case 6: case 8: case 10: case 12: return true; default: return false; }
+}
+
+int dispatch_front(uint32_t sps, const FrontArgs &fa, dim3 grid, hipStream_t s)
+{
+    switch (sps) {
+    case 3: launch_front<3>(fa, grid, s); break;
+    case 4: launch_front<4>(fa, grid, s); break;
+    case 5: launch_front<5>(fa, grid, s); break;
+    case 6: launch_front<6>(fa, grid, s); break;
+    case 8: launch_front<8>(fa, grid, s); break;
+    case 10: launch_front<10>(fa, grid, s); break;
+    case 12: launch_front<12>(fa, grid, s); break;
+    default: return -EINVAL;
+    }
+    return 0;
+}
+
+// the fused chain on channel-major device IQ: front -> carry -> resolve -> capture/decode
+int run_iq_device(amps_recc *h, const float2 *iq, uint64_t ld, uint32_t nsamp)
+{
+    if (nsamp == 0) return 0;
+    hipStream_t s = h->stream;
+    const uint32_t avail = h->r_prev + nsamp;
+    const uint32_t P = (avail / 64) * 64, r_new = avail - P;
+    const uint32_t chunk_samples = h->tiles_per_chunk * TILE;
+    const uint32_t nchunks = (P + chunk_samples - 1) / chunk_samples;
+    if (nchunks > h->max_chunks) return -E2BIG;
+    if (P) {
+        FrontArgs fa{};
+        fa.block = iq; fa.carry = h->carry[h->carry_cur]; fa.ld = ld;
+        fa.r_prev = h->r_prev; fa.avail = avail; fa.P = P; fa.tiles_per_chunk = h->tiles_per_chunk;
+        fa.n_done = h->n_done; fa.gring = h->gring; fa.ring_mask = h->ring_words - 1; fa.ring_words = h->ring_words;
+        fa.det = h->det; fa.detcount = h->detcount; fa.max_chunks = h->max_chunks; fa.det_cap = h->det_cap;
+        fa.status = h->status; fa.dbg_d = h->dbg_d; fa.dbg_S = h->dbg_S; fa.dbg_channel = 0;
+        SpanGuard g(h, T_FRONT, P);
+        int rc = dispatch_front(h->sps, fa, dim3(nchunks, h->C), s);
+        if (rc) return rc;
+    }
+    {
+        CarryArgs ca{};
+        ca.block = iq; ca.carry_in = h->carry[h->carry_cur]; ca.carry_out = h->carry[h->carry_cur ^ 1];
+        ca.ld = ld; ca.r_prev = h->r_prev; ca.avail = avail; ca.P = P; ca.r_new = r_new;
+        SpanGuard g(h, T_CARRY);
+        hipLaunchKernelGGL(recc_carry_kernel, dim3((HALO + r_new + 255) / 256, h->C), dim3(256), 0, s, ca);
+    }
+    if (P) {
+        HIP_TRY(hipMemsetAsync(h->capq_count, 0, sizeof(uint32_t), s));
+        ResolveArgs ra{};
+        ra.det = h->det; ra.detcount = h->detcount; ra.max_chunks = h->max_chunks; ra.det_cap = h->det_cap;
+        ra.nchunks = nchunks; ra.sps = h->sps; ra.n_proc = h->n_done + P;
+        ra.next_allowed = h->next_allowed; ra.pending = h->pending; ra.capq = h->capq; ra.capq_count = h->capq_count;
+        ra.capq_cap = h->cfg.max_bursts; ra.status = h->status;
+        {
+            SpanGuard g(h, T_RESOLVE);
+            hipLaunchKernelGGL(recc_resolve_kernel, dim3(h->C), dim3(64), 0, s, ra);
+        }
+        CaptureArgs ca{};
+        ca.capq = h->capq; ca.capq_count = h->capq_count; ca.capq_cap = h->cfg.max_bursts; ca.sps = h->sps;
+        ca.gring = h->gring; ca.ring_mask = h->ring_words - 1; ca.ring_words = h->ring_words;
+        ca.records = h->records; ca.nrecords = h->nrecords; ca.rec_cap = h->cfg.max_bursts; ca.status = h->status;
+        {
+            SpanGuard g(h, T_DECODE);
+            uint32_t grid = std::min<uint32_t>(h->cfg.max_bursts, 2048u);
+            hipLaunchKernelGGL(recc_capture_kernel, dim3(grid), dim3(64), 0, s, ca);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    h->n_done += P;
+    h->r_prev = r_new;
+    h->carry_cur ^= 1;
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int amps_recc_abi_version(void) { return AMPS_RECC_ABI_VERSION; }
+size_t amps_recc_burst_size(void) { return sizeof(amps_recc_burst_t); }
+
+const char *amps_recc_strerror(int code)
+{
+    switch (-code) {
+    case 0: return "ok";
+    case EINVAL: return "invalid argument";
+    case ENODEV: return "no usable HIP device (this library has no CPU fallback)";
+    case ENOMEM: return "out of device or host memory";
+    case EIO: return "HIP runtime error";
+    case ENOSPC: return "result list overflowed max_bursts";
+    case E2BIG: return "push larger than the configured capacity";
+    case EOVERFLOW: return "trigger-hit list overflowed";
+    case ENOSYS: return "seam not configured on this handle";
+    default: return "unknown error";
+    }
+}
+
+int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
+{
+    if (!out || !cfg) return -EINVAL;
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(amps_recc_cfg_t)) return -EINVAL;
+    if (cfg->n_channels < 1 || cfg->max_bursts < 1) return -EINVAL;
+    if (cfg->max_samples_per_push && !sps_supported(cfg->samples_per_symbol)) return -EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return -ENODEV;
+    int dev = cfg->device;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) return -ENODEV; }
+    if (dev >= ndev) return -ENODEV;
+    if (hipSetDevice(dev) != hipSuccess) return -ENODEV;
+
+    amps_recc *h = new (std::nothrow) amps_recc();
+    if (!h) return -ENOMEM;
+    h->cfg = *cfg;
+    h->device = dev;
+    h->C = cfg->n_channels;
+    h->sps = cfg->samples_per_symbol;
+    h->timing = (cfg->flags & AMPS_RECC_FLAG_TIME_KERNELS) != 0;
+    if (cfg->stream) h->stream = (hipStream_t)cfg->stream;
+    else {
+        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return -EIO; }
+        h->own_stream = true;
+    }
+    int rc = 0;
+    const size_t C = h->C;
+    // results + symbol seam (always present)
+    rc |= dev_alloc(&h->records, cfg->max_bursts);
+    rc |= dev_alloc(&h->nrecords, 1);
+    rc |= dev_alloc(&h->status, 1);
+    rc |= dev_alloc(&h->symbuf, C * AMPS_RECC_SYMBUF);
+    rc |= dev_alloc(&h->sym_len, C);
+    rc |= dev_alloc(&h->sym_cur, C);
+    rc |= dev_alloc(&h->sym_stage, C * (size_t)(AMPS_RECC_MAX_WORK_ITEMS + 1));
+    rc |= dev_alloc(&h->bursts_dev, (size_t)cfg->max_bursts * AMPS_RECC_CAPTURE_SYMS);
+    rc |= dev_alloc(&h->burst_chan_dev, cfg->max_bursts);
+    rc |= dev_alloc(&h->nbursts_dev, 1);
+    // IQ seam
+    if (!rc && cfg->max_samples_per_push) {
+        const uint64_t maxs = cfg->max_samples_per_push;
+        h->ring_words = next_pow2(maxs + (uint64_t)h->sps * (AMPS_RECC_CAPTURE_SYMS + 2 * AMPS_RECC_TRIGGER_SYMS + 64) + 2 * TILE) / 64;
+        const uint64_t max_tiles = (maxs + 63 + TILE - 1) / TILE + 1;
+        uint64_t tpc = (max_tiles * C) / 4096;              // aim for >= ~4096 workgroups per launch
+        tpc = std::max<uint64_t>(4, std::min<uint64_t>(32, tpc));
+        h->tiles_per_chunk = (uint32_t)tpc;
+        h->max_chunks = (uint32_t)((max_tiles + tpc - 1) / tpc);
+        h->det_cap = (uint32_t)(tpc * TILE / ((uint64_t)AMPS_RECC_TRIGGER_SYMS * h->sps) + 4);
+        rc |= dev_alloc(&h->carry[0], C * CARRY_CAP);
+        rc |= dev_alloc(&h->carry[1], C * CARRY_CAP);
+        rc |= dev_alloc(&h->gring, C * h->ring_words);
+        rc |= dev_alloc(&h->det, C * h->max_chunks * h->det_cap);
+        rc |= dev_alloc(&h->detcount, C * h->max_chunks);
+        rc |= dev_alloc(&h->next_allowed, C);
+        rc |= dev_alloc(&h->pending, C);
+        rc |= dev_alloc(&h->capq, cfg->max_bursts);
+        rc |= dev_alloc(&h->capq_count, 1);
+    }
+    if (!rc && cfg->wideband_channels) rc = channelizer_create(h->chz, *cfg, h->stream);
+    if (!rc) rc = reset_state(h);
+    if (rc) { amps_recc_destroy(h); return rc; }
+    *out = h;
+    return 0;
+}
+
+void amps_recc_destroy(amps_recc_t *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    collect_spans(h);
+    void *bufs[] = { h->carry[0], h->carry[1], h->gring, h->det, h->detcount, h->next_allowed, h->pending, h->capq,
+                     h->capq_count, h->records, h->nrecords, h->status, h->stage_iq, h->symbuf, h->sym_len, h->sym_cur,
+                     h->sym_stage, h->bursts_dev, h->burst_chan_dev, h->nbursts_dev, h->dec_out_dev, h->dec_in_dev,
+                     h->dec_chan_dev, h->dbg_d, h->dbg_S };
+    for (void *p : bufs) if (p) (void)hipFree(p);
+    channelizer_destroy(h->chz);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int amps_recc_reset(amps_recc_t *h)
+{
+    if (!h) return -EINVAL;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    collect_spans(h);
+    return reset_state(h);
+}
+
+int amps_recc_push_symbols(amps_recc_t *h, const uint8_t *syms, size_t ld, int n, int mem,
+                           uint8_t *bursts_out, uint32_t *burst_channel, size_t cap, size_t *nout)
+{
+    if (!h || !nout) return -EINVAL;
+    *nout = 0;
+    if (n < 1) return 0;                                   // lib/recc_impl.cc:99-102
+    if (n > AMPS_RECC_MAX_WORK_ITEMS) return -EINVAL;      // lib/recc_impl.cc:103
+    if (!syms || ld < (size_t)n) return -EINVAL;
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const uint8_t *dsyms = syms;
+    uint64_t dld = ld;
+    if (mem == AMPS_MEM_HOST) {
+        dld = AMPS_RECC_MAX_WORK_ITEMS + 1;
+        HIP_TRY(hipMemcpy2DAsync(h->sym_stage, dld, syms, ld, (size_t)n, h->C, hipMemcpyHostToDevice, s));
+        dsyms = h->sym_stage;
+    }
+    HIP_TRY(hipMemsetAsync(h->nbursts_dev, 0, sizeof(uint32_t), s));
+    SymbolsArgs a{};
+    a.syms = dsyms; a.ld = dld; a.n = n; a.symbuf = h->symbuf; a.len = h->sym_len; a.curstart = h->sym_cur;
+    a.bursts = h->bursts_dev; a.burst_chan = h->burst_chan_dev; a.nbursts = h->nbursts_dev;
+    a.cap = h->cfg.max_bursts; a.status = h->status;
+    {
+        SpanGuard g(h, T_SYMBOLS);
+        hipLaunchKernelGGL(recc_symbols_kernel, dim3(h->C), dim3(256), 0, s, a);
+    }
+    HIP_TRY(hipGetLastError());
+    uint32_t nb = 0;
+    HIP_TRY(hipMemcpyAsync(&nb, h->nbursts_dev, sizeof(nb), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    collect_spans(h);
+    int rc = 0;
+    if (nb > h->cfg.max_bursts) { nb = h->cfg.max_bursts; rc = -ENOSPC; }
+    if (nb == 0) return rc;
+    std::vector<uint32_t> chan(nb);
+    std::vector<uint8_t> data((size_t)nb * AMPS_RECC_CAPTURE_SYMS);
+    HIP_TRY(hipMemcpy(chan.data(), h->burst_chan_dev, sizeof(uint32_t) * nb, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(data.data(), h->bursts_dev, data.size(), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> order(nb);
+    for (uint32_t i = 0; i < nb; i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return chan[x] < chan[y]; });
+    size_t k = 0;
+    for (; k < nb && k < cap; k++) {
+        if (bursts_out) std::memcpy(bursts_out + k * AMPS_RECC_CAPTURE_SYMS, &data[(size_t)order[k] * AMPS_RECC_CAPTURE_SYMS], AMPS_RECC_CAPTURE_SYMS);
+        if (burst_channel) burst_channel[k] = chan[order[k]];
+    }
+    *nout = k;
+    if (nb > cap) rc = -ENOSPC;
+    return rc;
+}
+
+int amps_recc_decode_bursts(amps_recc_t *h, const uint8_t *bursts, size_t nbursts, int mem,
+                            const uint32_t *burst_channel, amps_recc_burst_t *out)
+{
+    if (!h || (!bursts && nbursts) || (!out && nbursts)) return -EINVAL;
+    if (nbursts == 0) return 0;
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    if (nbursts > h->dec_out_cap) {
+        if (h->dec_out_dev) (void)hipFree(h->dec_out_dev);
+        if (h->dec_in_dev) (void)hipFree(h->dec_in_dev);
+        if (h->dec_chan_dev) (void)hipFree(h->dec_chan_dev);
+        h->dec_out_dev = nullptr; h->dec_in_dev = nullptr; h->dec_chan_dev = nullptr; h->dec_out_cap = 0;
+        if (dev_alloc(&h->dec_out_dev, nbursts) || dev_alloc(&h->dec_in_dev, nbursts * AMPS_RECC_CAPTURE_SYMS) ||
+            dev_alloc(&h->dec_chan_dev, nbursts)) return -ENOMEM;
+        h->dec_out_cap = nbursts;
+    }
+    const uint8_t *din = bursts;
+    if (mem == AMPS_MEM_HOST) {
+        HIP_TRY(hipMemcpyAsync(h->dec_in_dev, bursts, nbursts * AMPS_RECC_CAPTURE_SYMS, hipMemcpyHostToDevice, s));
+        din = h->dec_in_dev;
+    }
+    const uint32_t *dchan = nullptr;
+    if (burst_channel) {
+        HIP_TRY(hipMemcpyAsync(h->dec_chan_dev, burst_channel, nbursts * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        dchan = h->dec_chan_dev;
+    }
+    {
+        SpanGuard g(h, T_DECODE);
+        uint32_t grid = (uint32_t)std::min<size_t>(nbursts, 4096);
+        hipLaunchKernelGGL(recc_decode_bursts_kernel, dim3(grid), dim3(64), 0, s, din, dchan, (uint32_t)nbursts, h->dec_out_dev);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, h->dec_out_dev, nbursts * sizeof(amps_recc_burst_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    collect_spans(h);
+    return 0;
+}
+
+int amps_recc_push_iq(amps_recc_t *h, const float *iq, size_t ld, size_t nsamp, int mem)
+{
+    if (!h) return -EINVAL;
+    if (!h->carry[0]) return -ENOSYS;
+    if (nsamp == 0) return 0;
+    if (!iq || ld < nsamp) return -EINVAL;
+    if (nsamp > h->cfg.max_samples_per_push) return -E2BIG;
+    HIP_TRY(hipSetDevice(h->device));
+    const float2 *d = (const float2 *)iq;
+    uint64_t dld = ld;
+    if (mem == AMPS_MEM_HOST) {
+        if (h->stage_iq_samples < (size_t)h->C * h->cfg.max_samples_per_push) {
+            if (h->stage_iq) (void)hipFree(h->stage_iq);
+            h->stage_iq = nullptr; h->stage_iq_samples = 0;
+            if (dev_alloc(&h->stage_iq, (size_t)h->C * h->cfg.max_samples_per_push)) return -ENOMEM;
+            h->stage_iq_samples = (size_t)h->C * h->cfg.max_samples_per_push;
+        }
+        dld = nsamp;
+        HIP_TRY(hipMemcpy2DAsync(h->stage_iq, dld * sizeof(float2), iq, ld * sizeof(float2), nsamp * sizeof(float2),
+                                 h->C, hipMemcpyHostToDevice, h->stream));
+        d = h->stage_iq;
+    }
+    return run_iq_device(h, d, dld, (uint32_t)nsamp);
+}
+
+int amps_recc_push_wideband(amps_recc_t *h, const float *iq, size_t nsamp, int mem)
+{
+    if (!h) return -EINVAL;
+    if (!h->chz.enabled) return -ENOSYS;
+    if (nsamp == 0) return 0;
+    if (!iq) return -EINVAL;
+    HIP_TRY(hipSetDevice(h->device));
+    const float2 *chan_iq = nullptr;
+    uint64_t ld = 0;
+    uint32_t nout = 0;
+    int rc;
+    {
+        SpanGuard g(h, T_CHANNELIZER, nsamp);
+        rc = channelizer_run(h->chz, (const float2 *)iq, nsamp, mem, h->stream, &chan_iq, &ld, &nout);
+    }
+    if (rc) return rc;
+    if (nout > h->cfg.max_samples_per_push) return -E2BIG;
+    return run_iq_device(h, chan_iq, ld, nout);
+}
+
+int amps_recc_drain(amps_recc_t *h, amps_recc_burst_t *out, size_t cap, size_t *nout)
+{
+    if (!h || !nout) return -EINVAL;
+    *nout = 0;
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    uint32_t hdr[2] = { 0, 0 };
+    HIP_TRY(hipMemcpyAsync(&hdr[0], h->nrecords, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&hdr[1], h->status, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    collect_spans(h);
+    uint32_t n = hdr[0];
+    int rc = 0;
+    if (hdr[1] & 1u) rc = -EOVERFLOW;
+    if ((hdr[1] & (2u | 4u)) || n > h->cfg.max_bursts) { rc = -ENOSPC; }
+    if (n > h->cfg.max_bursts) n = h->cfg.max_bursts;
+    if (n) {
+        std::vector<amps_recc_burst_t> tmp(n);
+        HIP_TRY(hipMemcpy(tmp.data(), h->records, sizeof(amps_recc_burst_t) * n, hipMemcpyDeviceToHost));
+        std::sort(tmp.begin(), tmp.end(), [](const amps_recc_burst_t &x, const amps_recc_burst_t &y) {
+            return x.channel != y.channel ? x.channel < y.channel : x.position < y.position;
+        });
+        size_t k = std::min<size_t>(n, cap);
+        if (out && k) std::memcpy(out, tmp.data(), k * sizeof(amps_recc_burst_t));
+        *nout = k;
+        if (n > cap) rc = -ENOSPC;
+    }
+    HIP_TRY(hipMemsetAsync(h->nrecords, 0, sizeof(uint32_t), s));
+    HIP_TRY(hipMemsetAsync(h->status, 0, sizeof(uint32_t), s));
+    return rc;
+}
+
+int amps_recc_debug_demod(amps_recc_t *h, const float *iq, size_t nsamp, int mem, float *demod, float *soft, uint8_t *hard)
+{
+    if (!h || !iq) return -EINVAL;
+    if (!h->carry[0]) return -ENOSYS;
+    if (nsamp == 0 || nsamp > h->cfg.max_samples_per_push) return -E2BIG;
+    int rc = amps_recc_reset(h);
+    if (rc) return rc;
+    const size_t P = (nsamp / 64) * 64;
+    if (dev_alloc(&h->dbg_d, nsamp) || dev_alloc(&h->dbg_S, nsamp)) return -ENOMEM;
+    // channel 0 only: replicate the single stream on every channel row is not needed, rows other than 0 read garbage-free zeros
+    std::vector<float> zeros;
+    const float *src = iq;
+    size_t ld = nsamp;
+    std::vector<float> tmp;
+    if (h->C > 1) {
+        if (mem != AMPS_MEM_HOST) { rc = -EINVAL; goto done; }
+        tmp.assign((size_t)h->C * nsamp * 2, 0.f);
+        std::memcpy(tmp.data(), iq, nsamp * 2 * sizeof(float));
+        src = tmp.data();
+    }
+    rc = amps_recc_push_iq(h, src, ld, nsamp, mem);
+    if (!rc) {
+        if (hipStreamSynchronize(h->stream) != hipSuccess) rc = -EIO;
+    }
+    if (!rc && P) {
+        if (demod && hipMemcpy(demod, h->dbg_d, P * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = -EIO;
+        if (soft && hipMemcpy(soft, h->dbg_S, P * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = -EIO;
+        if (hard) {
+            std::vector<uint64_t> ring(h->ring_words);
+            if (hipMemcpy(ring.data(), h->gring, sizeof(uint64_t) * h->ring_words, hipMemcpyDeviceToHost) != hipSuccess) rc = -EIO;
+            for (size_t i = 0; i < P; i++) hard[i] = (uint8_t)((ring[(i >> 6) & (h->ring_words - 1)] >> (i & 63)) & 1ull);
+        }
+    }
+done:
+    (void)hipFree(h->dbg_d); (void)hipFree(h->dbg_S);
+    h->dbg_d = nullptr; h->dbg_S = nullptr;
+    {
+        int rc2 = amps_recc_reset(h);
+        if (!rc) rc = rc2;
+    }
+    return rc;
+}
+
+int amps_recc_get_timing(amps_recc_t *h, amps_recc_timing_t *t, int reset)
+{
+    if (!h || !t) return -EINVAL;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    collect_spans(h);
+    std::memset(t, 0, sizeof(*t));
+    t->struct_size = sizeof(*t);
+    t->launches_front = h->launches_front;
+    t->ms_front = h->ms[T_FRONT] + h->ms[T_CHANNELIZER];
+    t->ms_resolve = h->ms[T_RESOLVE];
+    t->ms_decode = h->ms[T_DECODE];
+    t->ms_carry = h->ms[T_CARRY];
+    t->ms_symbols = h->ms[T_SYMBOLS];
+    t->samples_front = h->samples_front;
+    if (reset) {
+        for (double &m : h->ms) m = 0;
+        h->launches_front = 0;
+        h->samples_front = 0;
+    }
+    return 0;
+}
+
+// ---- reply generation: handle_response / handle_registration / handle_origination
+// (lib/recc_decode_impl.cc:181-272) with the TX word builders of lib/amps_packet.cc:26-95.
+// Host integer code, a few dozen byte stores per burst.
+static void put_bits(uint8_t *o, int n, uint64_t v) { for (int i = n - 1; i >= 0; i--) { o[i] = (uint8_t)(v & 1u); v >>= 1; } }
+static void word1(uint8_t *w, bool multi, unsigned dcc, uint64_t min1)
+{
+    w[0] = 0; w[1] = multi; w[2] = (dcc >> 1) & 1u; w[3] = dcc & 1u; put_bits(w + 4, 24, min1);
+}
+static void word2_general(uint8_t *w, uint64_t min2, unsigned msg_type, unsigned ordq, unsigned order)
+{
+    w[0] = 1; w[1] = 0; w[2] = 1; w[3] = 1; put_bits(w + 4, 10, min2); w[14] = 0;
+    put_bits(w + 15, 5, msg_type); put_bits(w + 20, 3, ordq); put_bits(w + 23, 5, order);
+}
+static void word2_voice(uint8_t *w, unsigned scc, uint64_t min2, unsigned vmac, unsigned chan)
+{
+    w[0] = 1; w[1] = 0; w[2] = (scc >> 1) & 1u; w[3] = scc & 1u; put_bits(w + 4, 10, min2);
+    put_bits(w + 14, 3, vmac); put_bits(w + 17, 11, chan);
+}
+static void fvc_general(uint8_t *w, unsigned pscc, unsigned msg_type, unsigned ordq, unsigned order)
+{
+    std::memset(w, 0, 28);
+    w[0] = 1; w[2] = 1; w[3] = 1; w[4] = (pscc >> 1) & 1u; w[5] = pscc & 1u;
+    put_bits(w + 15, 5, msg_type); put_bits(w + 20, 3, ordq); put_bits(w + 23, 5, order);
+}
+
+int amps_recc_reply_words(const amps_recc_burst_t *b, amps_recc_reply_t *r)
+{
+    if (!b || !r) return -EINVAL;
+    std::memset(r, 0, sizeof(*r));
+    const unsigned DCC = 0, SCC = 1;     // GLOBAL_DCC_SHORT, GLOBAL_SCC (lib/amps_packet.h:13-14)
+    const int STREAM_BOTH = 3;           // lib/amps_packet.h:33 (the A/B choice at :240-245 is overridden at :247)
+    switch (b->msg_class) {
+    case AMPS_MSG_REGISTRATION:          // :181-190 order confirmation = audit order 7
+        r->has_focc = 1; r->focc_stream = STREAM_BOTH; r->focc_nwords = 2;
+        word1(r->focc_word1, true, DCC, b->a_MIN1);
+        word2_general(r->focc_word2, b->b_MIN2, 0, 0, 7);
+        break;
+    case AMPS_MSG_PAGE_RESPONSE:         // :195-222 voice channel 355, alert on the FVC
+        r->has_focc = 1; r->focc_stream = STREAM_BOTH; r->focc_nwords = 2;
+        word1(r->focc_word1, true, DCC, b->a_MIN1);
+        word2_voice(r->focc_word2, SCC, b->b_MIN2, 0, 355);
+        r->has_fvc = 1; r->fvc_count = 1; r->fvc_repeat = 35;
+        fvc_general(r->fvc_word1, SCC, 0, 0, 1);
+        r->has_mutes = 1; r->fvc_mute = 0; r->audio_mute = 1;
+        break;
+    case AMPS_MSG_ORIGINATION:           // :236-272 voice channel 356 (or reorder 9 for a leading '0')
+        r->has_focc = 1; r->focc_stream = STREAM_BOTH; r->focc_nwords = 2;
+        word1(r->focc_word1, true, DCC, b->a_MIN1);
+        if (b->dialed[0] == '0') word2_general(r->focc_word2, b->b_MIN2, 0, 0, 9);
+        else word2_voice(r->focc_word2, SCC, b->b_MIN2, 0, 356);
+        r->has_mutes = 1; r->fvc_mute = 1; r->audio_mute = 0;
+        r->has_command = 1;
+        std::snprintf(r->command, sizeof(r->command), "page %.*s", 32, b->dialed);
+        break;
+    default: break;
+    }
+    return 0;
+}
+
+} // extern "C"

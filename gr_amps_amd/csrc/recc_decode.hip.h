@@ -1,0 +1,270 @@
+// recc_decode.hip.h -- device-side recc_decode core for gfx950 (one 64-lane wavefront per burst).
+//
+// Replaces, on the device, the per-burst work of the reference's recc_decode block:
+//   manchester_decode_binbuf      lib/utils.cc:27-59
+//   recc_bch_decode / itpp::BCH   lib/recc_decode_impl.cc:53-79 (BCH(63,51,t=2) shortened to (48,36))
+//   bursts_message word loop      lib/recc_decode_impl.cc:96-107 (first valid repeat of 5)
+//   recc_word_a/_b/_c/_called     lib/amps_packet.h:103-274, calc_min :277-302,354-363
+//   dispatch                      lib/recc_decode_impl.cc:108-168
+//
+// Design notes (MI355X): a burst is 3374 symbol bytes -> 1687 bits -> 35 BCH blocks.  One wave
+// handles one burst: the 64 lanes stride over the symbol pairs (Manchester), lanes 0..34 each
+// decode one 48-bit block algebraically (syndromes S1,S3 in GF(64) from a 63-entry constant table,
+// closed-form locator for t=2, 63-step root count), lanes 0..6 pick the first valid repeat, and
+// the record is written back cooperatively.  Everything stays in LDS (3.4 KB symbols + 1.7 KB
+// bits); bursts are rare events (<= 1 per 34 480 samples per channel), so this kernel is latency-
+// not bandwidth-critical and is kept simple.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "amps_recc.h"
+
+namespace amps {
+
+// ---- GF(64), primitive polynomial x^6 + x + 1 (the field IT++ uses for q = 64) ----
+struct Gf64Tables {
+    uint8_t exp[128];
+    uint8_t log[64];
+};
+constexpr Gf64Tables make_gf64()
+{
+    Gf64Tables t{};
+    unsigned v = 1;
+    for (int i = 0; i < 63; i++) {
+        t.exp[i] = (uint8_t)v;
+        t.exp[i + 63] = (uint8_t)v;
+        t.log[v] = (uint8_t)i;
+        v <<= 1;
+        if (v & 0x40) v ^= 0x43;
+    }
+    t.exp[126] = t.exp[0];
+    t.exp[127] = t.exp[1];
+    t.log[0] = 0;
+    return t;
+}
+__constant__ Gf64Tables c_gf = make_gf64();
+
+__device__ __forceinline__ unsigned gf_mul(unsigned a, unsigned b)
+{
+    return (a && b) ? c_gf.exp[c_gf.log[a] + c_gf.log[b]] : 0u;
+}
+__device__ __forceinline__ unsigned gf_div(unsigned a, unsigned b) // b != 0
+{
+    return a ? c_gf.exp[c_gf.log[a] + 63 - c_gf.log[b]] : 0u;
+}
+
+// Result of decoding one 48-bit block: ok + up to 3 error exponents (coefficient of x^e flips).
+struct BchResult {
+    int ok;
+    int nflip;
+    int e[3];
+};
+
+// bits: 48 bytes (0/1), bit i is the coefficient of x^(47-i); the 15 shortening zeros sit at x^48..x^62.
+// Semantics = IT++ BCH(63,2,true)::decode: syndromes, two Berlekamp steps (closed form for t = 2),
+// root search over all 63 positions, failure iff #roots != deg(Lambda).  Roots in the 15 padding
+// positions are NOT rejected (the reference does not check them).
+__device__ inline BchResult bch4836_decode(const uint8_t *bits)
+{
+    BchResult r;
+    r.ok = 0; r.nflip = 0; r.e[0] = r.e[1] = r.e[2] = -1;
+    unsigned S1 = 0, S3 = 0;
+    for (int i = 0; i < 48; i++) {
+        if (bits[i] & 1u) {
+            int e = 47 - i;
+            S1 ^= c_gf.exp[e];
+            S3 ^= c_gf.exp[(3 * e) % 63];
+        }
+    }
+    if ((S1 | S3) == 0) { r.ok = 1; return r; }
+    if (S1 != 0) {
+        unsigned S1cube = gf_mul(gf_mul(S1, S1), S1);
+        unsigned delta = S3 ^ S1cube;            // Omega[3] = S3 + S1*S2, S2 = S1^2
+        if (delta == 0) {                        // Lambda = 1 + S1 x : single error at log(S1)
+            r.ok = 1; r.nflip = 1; r.e[0] = c_gf.log[S1];
+            return r;
+        }
+        unsigned c2 = gf_div(delta, S1);         // Lambda = 1 + S1 x + (delta/S1) x^2
+        int found = 0;
+        for (int j = 0; j < 63; j++) {
+            unsigned v = 1u ^ gf_mul(S1, c_gf.exp[j]) ^ gf_mul(c2, c_gf.exp[(2 * j) % 63]);
+            if (v == 0 && found < 3) r.e[found++] = (63 - j) % 63;
+        }
+        if (found == 2) { r.ok = 1; r.nflip = 2; }
+        return r;
+    }
+    // S1 == 0, S3 != 0: first step leaves Lambda = 1 and T = x^2, second gives Lambda = 1 + S3 x^3
+    {
+        int found = 0;
+        for (int j = 0; j < 63; j++) {
+            unsigned v = 1u ^ gf_mul(S3, c_gf.exp[(3 * j) % 63]);
+            if (v == 0 && found < 3) r.e[found++] = (63 - j) % 63;
+        }
+        if (found == 3) { r.ok = 1; r.nflip = 3; }
+    }
+    return r;
+}
+
+__device__ __forceinline__ unsigned getbits(const uint8_t *b, int n)
+{
+    unsigned v = 0;
+    for (int i = 0; i < n; i++) v = (v << 1) | (b[i] & 1u);
+    return v;
+}
+
+// lib/amps_packet.h:277-302 (quirks kept: dig>9 -> 0)
+__device__ inline void extract_min_3(unsigned val, char *out)
+{
+    unsigned m2 = val + 111;
+    unsigned dig = m2 % 10;
+    out[2] = (char)('0' + dig);
+    if (dig == 0) m2 -= 10; else m2 -= dig;
+    dig = (m2 % 100) / 10;
+    out[1] = (char)('0' + dig);
+    if (dig == 0) m2 -= 100; else m2 -= (m2 % 100);
+    dig = m2 / 100;
+    if (dig > 9) dig = 0;
+    out[0] = (char)('0' + dig);
+}
+
+// LDS scratch one wave needs to decode a burst
+struct DecodeScratch {
+    uint8_t  sym[AMPS_RECC_CAPTURE_SYMS + 2];   // symbol bytes
+    uint8_t  bits[1688];                        // dcc(7) + 7*240
+    uint32_t bad[8];                            // [0]=dcc, [1+w]=word w
+    uint32_t nonbin;
+    int8_t   ok[35];
+    int8_t   flip[35][3];
+    amps_recc_burst_t rec;                      // staged record (728 B), copied out coalesced
+};
+
+// Decode the burst held in s.sym; all 64 lanes of ONE wave must call this (blockDim.x == 64).
+__device__ inline void decode_burst_wave(DecodeScratch &s, uint32_t channel, uint64_t position,
+                                         amps_recc_burst_t *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    if (lane < 8) s.bad[lane] = 0;
+    if (lane == 8) s.nonbin = 0;
+    // zero the staged record
+    for (int i = lane; i < (int)(sizeof(amps_recc_burst_t) / 4); i += 64) ((uint32_t *)&s.rec)[i] = 0;
+    __syncthreads();
+
+    // ---- Manchester decode, lib/utils.cc:27-59 ----
+    for (int k = lane; k < 1687; k += 64) {
+        unsigned a = s.sym[2 * k], b = s.sym[2 * k + 1];
+        unsigned sval = (a << 8) | b;
+        uint8_t bit; int bad = 0;
+        if (sval == 0x100) bit = 0;
+        else if (sval == 0x001) bit = 1;
+        else if (sval == 0x101) { bit = 0; bad = 1; }
+        else if (sval == 0x000) { bit = 1; bad = 1; }
+        else { bit = 0; bad = 1; atomicOr(&s.nonbin, 1u); }   // reference: assert(0), undefined in Release
+        s.bits[k] = bit;
+        if (bad) atomicAdd(&s.bad[k < 7 ? 0 : 1 + (k - 7) / 240], 1u);
+    }
+    __syncthreads();
+
+    // ---- BCH: 7 words x 5 repeats, lib/recc_decode_impl.cc:100-107 ----
+    if (lane < 35) {
+        const int w = lane / 5, r = lane % 5;
+        BchResult br = bch4836_decode(&s.bits[7 + 240 * w + 48 * r]);
+        s.ok[lane] = (int8_t)br.ok;
+        s.flip[lane][0] = (int8_t)br.e[0];
+        s.flip[lane][1] = (int8_t)br.e[1];
+        s.flip[lane][2] = (int8_t)br.e[2];
+    }
+    __syncthreads();
+
+    amps_recc_burst_t &o = s.rec;
+    if (lane < 7) {
+        const int w = lane;
+        int r = 0, ok = 0;
+        for (; r < 5; r++) if (s.ok[w * 5 + r]) { ok = 1; break; }
+        o.valid[w] = (uint8_t)ok;
+        o.first_valid_rep[w] = (uint8_t)r;
+        o.manch_bad[w] = (uint16_t)s.bad[1 + w];
+        const int rr = ok ? r : 4;
+        const uint8_t *src = &s.bits[7 + 240 * w + 48 * rr];
+        for (int i = 0; i < 36; i++) o.word_dec[w][i] = src[i];
+        if (ok) {
+            for (int f = 0; f < 3; f++) {
+                int e = s.flip[w * 5 + rr][f];
+                if (e >= 12 && e <= 47) o.word_dec[w][47 - e] ^= 1u;
+            }
+        }
+    }
+    // raw repeat 0 of every word (what the reference parses) + dcc
+    for (int i = lane; i < 7 * 48; i += 64) o.word_raw[i / 48][i % 48] = s.bits[7 + 240 * (i / 48) + (i % 48)];
+    if (lane < 7) o.dcc[lane] = s.bits[lane];
+    __syncthreads();
+
+    // ---- field parse + dispatch: one lane, negligible work (lib/amps_packet.h, recc_decode_impl.cc:108-168) ----
+    if (lane == 0) {
+        o.channel = channel;
+        o.position = position;
+        o.flags = s.nonbin ? AMPS_BURST_FLAG_NONBINARY : 0u;
+        o.dcc_bad = (uint8_t)s.bad[0];
+        const uint8_t *A = o.word_raw[0], *B = o.word_raw[1];
+        o.a_F = A[0] & 1u; o.a_NAWC = (uint8_t)getbits(A + 1, 3);
+        o.a_T = A[4] & 1u; o.a_S = A[5] & 1u; o.a_E = A[6] & 1u; o.a_ER = A[7] & 1u;
+        o.a_SCM = (uint8_t)getbits(A + 8, 4); o.a_MIN1 = getbits(A + 12, 24);
+        o.b_F = B[0] & 1u; o.b_NAWC = (uint8_t)getbits(B + 1, 3);
+        o.b_MSG_TYPE = (uint8_t)getbits(B + 4, 5); o.b_ORDQ = (uint8_t)getbits(B + 9, 3);
+        o.b_ORDER = (uint8_t)getbits(B + 12, 5); o.b_LT = B[17] & 1u; o.b_EP = B[18] & 1u;
+        o.b_SCM4 = B[19]; o.b_MPCI = (uint8_t)getbits(B + 20, 2); o.b_SDCC1 = (uint8_t)getbits(B + 22, 2);
+        o.b_SDCC2 = (uint8_t)getbits(B + 24, 2); o.b_MIN2 = (uint16_t)getbits(B + 26, 10);
+        // calc_min, lib/amps_packet.h:354-363
+        extract_min_3(o.b_MIN2, o.min);
+        extract_min_3((o.a_MIN1 >> 14) & 0x3ff, o.min + 3);
+        unsigned thous = (o.a_MIN1 >> 10) & 0xf;
+        if (thous > 9) thous = 0;
+        o.min[6] = (char)('0' + thous);
+        extract_min_3(o.a_MIN1 & 0x3ff, o.min + 7);
+
+        const bool zero_order = (o.b_ORDER == 0 && o.b_ORDQ == 0 && o.b_MSG_TYPE == 0);
+        if (!o.valid[0]) o.msg_class = AMPS_MSG_INVALID_WORD_A;
+        else if (!o.a_E) o.msg_class = AMPS_MSG_E_ZERO;
+        else if (o.a_T == 0 && zero_order) o.msg_class = AMPS_MSG_PAGE_RESPONSE;
+        else if (o.a_T == 1 && o.b_ORDER == 0xd) {
+            o.msg_class = AMPS_MSG_REGISTRATION;
+            o.has_esn = o.a_S;
+            if (o.a_S && o.a_NAWC > 1) {
+                const uint8_t *Cw = o.word_raw[2];
+                o.esn = getbits(Cw + 4, 32);
+                uint8_t nawc = (uint8_t)(o.a_NAWC - 2);
+                if ((uint8_t)getbits(Cw + 1, 3) != nawc) o.flags |= AMPS_BURST_FLAG_WORDC_NAWC_MISMATCH;
+            }
+        } else if (o.a_T == 1 && (o.a_NAWC > 2 || zero_order)) {
+            uint8_t nawc = o.a_NAWC;
+            unsigned next = 2;
+            o.has_esn = o.a_S;
+            if (o.a_S) {
+                const uint8_t *Cw = o.word_raw[next++];
+                o.esn = getbits(Cw + 4, 32);
+                nawc = (uint8_t)(o.a_NAWC - 2);
+                if ((uint8_t)getbits(Cw + 1, 3) != nawc) o.flags |= AMPS_BURST_FLAG_WORDC_NAWC_MISMATCH;
+            }
+            if (nawc < 1 || nawc > 4) o.msg_class = AMPS_MSG_BAD_NAWC;
+            else {
+                o.msg_class = AMPS_MSG_ORIGINATION;
+                int dl = 0;
+                for (; nawc > 0; nawc--) {
+                    unsigned digs = getbits(o.word_raw[next++] + 4, 32);
+                    for (int i = 0; i < 8; i++) {       // recc_word_called::digits(), amps_packet.h:211-273
+                        unsigned v = (digs >> 28) & 0xf;
+                        if (v == 0) break;
+                        if (v >= 13) { o.flags |= AMPS_BURST_FLAG_BAD_DIGIT; break; }
+                        o.dialed[dl++] = v <= 9 ? (char)('0' + v) : v == 10 ? '0' : v == 11 ? '*' : '#';
+                        digs <<= 4;
+                    }
+                    o.n_called_words++;
+                }
+            }
+        } else o.msg_class = AMPS_MSG_UNKNOWN;
+    }
+    __syncthreads();
+    // coalesced copy of the staged record to HBM
+    for (int i = lane; i < (int)(sizeof(amps_recc_burst_t) / 4); i += 64) ((uint32_t *)out)[i] = ((const uint32_t *)&s.rec)[i];
+}
+
+} // namespace amps

@@ -1,0 +1,137 @@
+// recc_resolve.hip.h -- per-channel ordering of trigger hits, burst hold-off, capture and decode.
+//
+// What the reference does serially inside recc_impl::work once memmem has hit
+// (lib/recc_impl.cc:121-139: wait until more than 3374 symbols follow, publish them, resume the
+// search after the captured region) becomes two small kernels that run after the streaming front
+// kernel on the same stream:
+//   recc_resolve_kernel  one wave per channel: walks the channel's ordered hit list, drops hits that
+//                        fall inside an accepted burst (hold-off = 74+3374 symbols), picks the centre
+//                        of the run of matching sample phases as the symbol timing, and either queues
+//                        the capture or parks it as "pending" until its tail has been received.
+//   recc_capture_kernel  one wave per queued capture: gathers the 3374 slicer bits at the chosen
+//                        phase from the channel's HBM bit ring, then runs the recc_decode core
+//                        (recc_decode.hip.h) and appends the record.
+// Both are latency-bound bookkeeping on kilobytes; the HBM-bound work is in recc_front.hip.h.
+#pragma once
+#include "recc_decode.hip.h"
+
+namespace amps {
+
+struct ResolveArgs {
+    const uint64_t *det;       // [C][max_chunks][det_cap]
+    const uint32_t *detcount;  // [C][max_chunks]
+    uint32_t max_chunks, det_cap, nchunks;
+    uint32_t sps;
+    uint64_t n_proc;           // absolute samples processed after this push
+    uint64_t *next_allowed;    // [C]
+    uint64_t *pending;         // [C], ~0 = none (holds n_c)
+    uint2    *capq_chan;       // unused
+    uint64_t *capq;            // [capq_cap] (channel << 40 | n_c)  -- n_c < 2^40 samples
+    uint32_t *capq_count;      // atomic
+    uint32_t capq_cap;
+    uint32_t *status;          // bit 1: capture queue overflow
+};
+
+__global__ __launch_bounds__(64) void recc_resolve_kernel(ResolveArgs a)
+{
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const uint64_t span_hold = (uint64_t)a.sps * (AMPS_RECC_CAPTURE_SYMS + AMPS_RECC_TRIGGER_SYMS);
+    const uint64_t span_done = (uint64_t)a.sps * (AMPS_RECC_CAPTURE_SYMS + 1);
+    uint64_t next_allowed = a.next_allowed[c];
+    uint64_t pend = a.pending[c];
+
+    auto enqueue = [&](uint64_t nc) {   // called uniformly; lane 0 appends
+        if (lane == 0) {
+            uint32_t slot = atomicAdd(a.capq_count, 1u);
+            if (slot < a.capq_cap) a.capq[slot] = ((uint64_t)c << 40) | nc;
+            else atomicOr(a.status, 2u);
+        }
+    };
+
+    if (pend != ~0ull && pend + span_done < a.n_proc) { enqueue(pend); pend = ~0ull; }
+
+    const uint32_t *cnt = a.detcount + (uint64_t)c * a.max_chunks;
+    const uint64_t *det = a.det + (uint64_t)c * a.max_chunks * a.det_cap;
+    for (uint32_t cb = 0; cb < a.nchunks; cb += 64) {
+        uint32_t ch = cb + lane;
+        uint32_t n = ch < a.nchunks ? cnt[ch] : 0u;
+        uint64_t any = __ballot(n != 0);
+        while (any) {                                 // chunks in order, hits in order (both rare)
+            int l = __ffsll((unsigned long long)any) - 1;
+            any &= any - 1;
+            uint32_t nl = __shfl(n, l);
+            const uint64_t *d = det + (uint64_t)(cb + l) * a.det_cap;
+            for (uint32_t b = 0; b < nl; b += 64) {
+                uint64_t e = (b + lane < nl) ? d[b + lane] : 0ull;
+                uint32_t m = nl - b < 64 ? nl - b : 64;
+                for (uint32_t i = 0; i < m; i++) {
+                    uint64_t ei = __shfl(e, (int)i);
+                    uint64_t astart = ei >> 8;
+                    uint32_t last = (uint32_t)(ei & 0xff);
+                    if (astart < next_allowed) continue;      // inside an accepted burst
+                    uint64_t nc = astart + last / 2;          // centre of the run of matching phases
+                    next_allowed = nc + span_hold;
+                    if (nc + span_done < a.n_proc) enqueue(nc);
+                    else pend = nc;                           // tail not received yet
+                }
+            }
+        }
+    }
+    if (lane == 0) { a.next_allowed[c] = next_allowed; a.pending[c] = pend; }
+}
+
+struct CaptureArgs {
+    const uint64_t *capq;
+    const uint32_t *capq_count;
+    uint32_t capq_cap;
+    uint32_t sps;
+    const uint64_t *gring;
+    uint32_t ring_mask, ring_words;
+    amps_recc_burst_t *records;
+    uint32_t *nrecords;       // atomic
+    uint32_t rec_cap;
+    uint32_t *status;         // bit 2: record list overflow
+};
+
+__global__ __launch_bounds__(64) void recc_capture_kernel(CaptureArgs a)
+{
+    __shared__ DecodeScratch s;
+    __shared__ uint32_t s_slot;
+    const int lane = threadIdx.x;
+    uint32_t ncap = *a.capq_count;
+    if (ncap > a.capq_cap) ncap = a.capq_cap;
+    for (uint32_t q = blockIdx.x; q < ncap; q += gridDim.x) {
+        const uint64_t e = a.capq[q];
+        const uint32_t c = (uint32_t)(e >> 40);
+        const uint64_t nc = e & ((1ull << 40) - 1);
+        const uint64_t *ring = a.gring + (uint64_t)c * a.ring_words;
+        for (int i = lane; i < AMPS_RECC_CAPTURE_SYMS; i += 64) {
+            uint64_t n = nc + (uint64_t)a.sps * (uint64_t)(i + 1);
+            uint64_t w = ring[(n >> 6) & a.ring_mask];
+            s.sym[i] = (uint8_t)((w >> (n & 63)) & 1ull);
+        }
+        if (lane == 0) s_slot = atomicAdd(a.nrecords, 1u);
+        __syncthreads();
+        const uint32_t slot = s_slot;
+        if (slot < a.rec_cap) decode_burst_wave(s, c, nc, a.records + slot);
+        else { if (lane == 0) atomicOr(a.status, 4u); }
+        __syncthreads();
+    }
+}
+
+// recc_decode core on a batch of 3374-byte bursts (amps_recc_decode_bursts)
+__global__ __launch_bounds__(64) void recc_decode_bursts_kernel(const uint8_t *bursts, const uint32_t *chan,
+                                                                uint32_t nbursts, amps_recc_burst_t *out)
+{
+    __shared__ DecodeScratch s;
+    const int lane = threadIdx.x;
+    for (uint32_t q = blockIdx.x; q < nbursts; q += gridDim.x) {
+        const uint8_t *b = bursts + (uint64_t)q * AMPS_RECC_CAPTURE_SYMS;
+        for (int i = lane; i < AMPS_RECC_CAPTURE_SYMS; i += 64) s.sym[i] = b[i];
+        __syncthreads();
+        decode_burst_wave(s, chan ? chan[q] : 0u, 0ull, out + q);
+        __syncthreads();
+    }
+}
+
+} // namespace amps

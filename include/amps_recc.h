@@ -1,0 +1,192 @@
+/* amps_recc.h -- C ABI of the MI355X-native AMPS reverse-control-channel (RECC) receive path.
+ *
+ * This is the drop-in boundary.  Every entry point replaces one
+ * interface of the reference (unsynchronized/gr-amps); citations are file:line under the
+ * reference tree:
+ *
+ *   amps_recc_push_symbols      <-  gr::amps::recc_impl::work            lib/recc_impl.cc:93-145
+ *                                   (io signature: 1 x unsigned char in, lib/recc_impl.cc:71-73;
+ *                                    "bursts" blob of 3374 bytes out,    lib/recc_impl.cc:82,126)
+ *   amps_recc_decode_bursts     <-  recc_decode_impl::bursts_message     lib/recc_decode_impl.cc:81-169
+ *                                   recc_decode_impl::recc_bch_decode    lib/recc_decode_impl.cc:53-79
+ *                                   manchester_decode_binbuf             lib/utils.cc:27-59
+ *                                   recc_word_a/_b/_c_serial/_called     lib/amps_packet.h:103-274
+ *                                   extract_min_3 / calc_min             lib/amps_packet.h:277-302,354-366
+ *   amps_recc_push_iq / _drain  <-  the flow-graph sub-chain  quadrature_demod_cf -> clock_recovery_mm_ff
+ *                                   -> binary_slicer_fb -> amps_recc -> amps_recc_decode
+ *                                   (grc/recctest.grc:458,846-874,807,310,349 and connections :3238-3274)
+ *   amps_recc_push_wideband     <-  N x (freq_xlating_fir_filter_ccc -> the chain above), one per 30 kHz
+ *                                   channel (grc/recctest.grc:889-937); polyphase channelizer front end
+ *   amps_recc_reply_words       <-  handle_response / handle_registration / handle_origination
+ *                                   lib/recc_decode_impl.cc:181-272 + word builders lib/amps_packet.cc:26-95
+ *
+ * Conventions: plain C types only; every function returns 0 on success or a negative errno-style
+ * code (never throws, never aborts); one handle is single-threaded (same rule as a GNU Radio block,
+ * SURVEY.md 8b "Threading"); all compute runs in hand-written HIP kernels on the handle's device --
+ * there is NO CPU fallback: without a usable HIP device amps_recc_create() fails with -ENODEV.
+ */
+#ifndef AMPS_RECC_H
+#define AMPS_RECC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMPS_RECC_ABI_VERSION 1
+
+/* protocol constants of the reference */
+#define AMPS_RECC_TRIGGER_SYMS 74   /* lib/recc_impl.cc:76-77: 37 bits x 2 Manchester symbols   */
+#define AMPS_RECC_CAPTURE_SYMS 3374 /* lib/recc_impl.cc:70: (7 + 7*240) bits x 2                */
+#define AMPS_RECC_WORDS        7    /* lib/recc_decode_impl.cc:92                                */
+#define AMPS_RECC_REPEATS      5    /* lib/recc_decode_impl.cc:101                               */
+#define AMPS_RECC_WORD_BITS    48   /* BCH(48,36) = BCH(63,51) shortened by 15                   */
+#define AMPS_RECC_MSG_BITS     36
+#define AMPS_RECC_SYMBUF       65536 /* lib/recc_impl.cc:68 d_symbufsz                           */
+#define AMPS_RECC_WINDOW       4096  /* lib/recc_impl.cc:69 d_windowsz                           */
+#define AMPS_RECC_MAX_WORK_ITEMS 61439 /* lib/recc_impl.cc:103: noutput_items < bufsz - windowsz */
+
+/* where a data pointer lives */
+#define AMPS_MEM_HOST   0
+#define AMPS_MEM_DEVICE 1
+
+/* amps_recc_cfg_t.flags */
+#define AMPS_RECC_FLAG_TIME_KERNELS 0x1u /* record HIP events around every kernel (amps_recc_get_timing) */
+
+/* message classes, the branches of lib/recc_decode_impl.cc:108-168 */
+enum amps_recc_msg_class {
+    AMPS_MSG_INVALID_WORD_A = 0, /* validwords[0]==false  -> dropped   (:108-111) */
+    AMPS_MSG_E_ZERO         = 1, /* worda.E==false        -> dropped   (:113-116) */
+    AMPS_MSG_PAGE_RESPONSE  = 2, /* handle_response                    (:121-122) */
+    AMPS_MSG_REGISTRATION   = 3, /* handle_registration                (:123-138) */
+    AMPS_MSG_ORIGINATION    = 4, /* handle_origination                 (:139-165) */
+    AMPS_MSG_BAD_NAWC       = 5, /* origination with nawc outside 1..4 (:155-158) */
+    AMPS_MSG_UNKNOWN        = 6  /* "got unknown RECC message"         (:166-168) */
+};
+
+/* amps_recc_burst_t.flags */
+#define AMPS_BURST_FLAG_NONBINARY 0x1u /* a symbol byte outside {0,1} was seen (reference: assert(0), UB in Release) */
+#define AMPS_BURST_FLAG_WORDC_NAWC_MISMATCH 0x2u /* "protocol violation" warning of :134-136 / :150-152 */
+#define AMPS_BURST_FLAG_BAD_DIGIT 0x4u /* digit code 13..15 truncated a called-address word (amps_packet.h:219-223) */
+
+/* One decoded seizure burst.  Bits are one byte per bit (0/1), MSB first, exactly as the reference
+ * holds them (lib/recc_decode_impl.cc:92-95).  Layout is fixed: natural alignment, 728 bytes. */
+typedef struct amps_recc_burst {
+    uint32_t channel;        /* RECC instance index                                                     */
+    uint32_t flags;          /* AMPS_BURST_FLAG_*                                                       */
+    uint64_t position;       /* symbol seam: 0.  IQ seams: absolute sample index of the last trigger
+                                symbol's decision instant (capture symbol i is sliced at position+sps*(i+1)) */
+    uint8_t  dcc[7];         /* manchester_decode_binbuf(bdata, dcc, 7)            (:90)               */
+    uint8_t  dcc_bad;        /* its return value (bad Manchester pairs)                                 */
+    uint16_t manch_bad[AMPS_RECC_WORDS];                 /* errs[i]                 (:97)               */
+    uint8_t  valid[AMPS_RECC_WORDS];                     /* validwords[w]           (:102)              */
+    uint8_t  first_valid_rep[AMPS_RECC_WORDS];           /* r at the break, 5 if none valid            */
+    uint8_t  word_raw[AMPS_RECC_WORDS][AMPS_RECC_WORD_BITS]; /* words[w][0..47]: repeat 0, uncorrected --
+                                                            what the reference parses (:112,117,130,146,161) */
+    uint8_t  word_dec[AMPS_RECC_WORDS][AMPS_RECC_MSG_BITS];  /* corrected message bits of the first valid
+                                                            repeat; uncorrected bits of repeat 4 if none   */
+    /* ---- parsed fields (lib/amps_packet.h:103-198), always from word_raw like the reference ---- */
+    uint8_t  a_F, a_NAWC, a_T, a_S, a_E, a_ER, a_SCM, _pad0;
+    uint32_t a_MIN1;
+    uint8_t  b_F, b_NAWC, b_MSG_TYPE, b_ORDQ, b_ORDER, b_LT, b_EP, b_SCM4, b_MPCI, b_SDCC1, b_SDCC2, _pad1;
+    uint16_t b_MIN2;
+    uint16_t _pad2;
+    uint32_t esn;            /* recc_word_c_serial::SERIAL when read, else 0                            */
+    uint8_t  has_esn;        /* registration: worda.S (:128); origination: worda.S (:145)               */
+    uint8_t  msg_class;      /* enum amps_recc_msg_class                                                */
+    uint8_t  n_called_words; /* origination: number of called-address words consumed                    */
+    uint8_t  _pad3;
+    char     min[12];        /* calc_min(): 10 digits, NUL padded                                        */
+    char     dialed[36];     /* concatenated recc_word_called::digits(), NUL padded (<= 32 chars)        */
+    uint32_t _pad4;
+} amps_recc_burst_t;
+#define AMPS_RECC_BURST_BYTES 728
+
+typedef struct amps_recc_cfg {
+    uint32_t struct_size;          /* sizeof(amps_recc_cfg_t), for ABI evolution                          */
+    uint32_t n_channels;           /* independent RECC instances handled per push (>=1)                   */
+    uint32_t samples_per_symbol;   /* IQ seam: samples per Manchester symbol (10 at 200 ksps); 2..16      */
+    uint32_t max_samples_per_push; /* IQ seam: capacity per channel per push (0 = IQ seam unused)         */
+    uint32_t max_bursts;           /* capacity of the device-side result list per push/drain (>=1)        */
+    int32_t  device;               /* HIP device ordinal, -1 = current device                             */
+    uint32_t flags;                /* AMPS_RECC_FLAG_*                                                    */
+    uint32_t wideband_channels;    /* channelizer seam: M branches (power of two, 0 = unused)             */
+    uint32_t wideband_decim;       /* channelizer seam: D input samples per output frame (M % D == 0)     */
+    uint32_t wideband_taps_per_branch; /* prototype length = taps_per_branch * M                         */
+    uint32_t wideband_first_channel;   /* first FFT bin that is an active RECC channel                    */
+    uint32_t _reserved;
+    void    *stream;               /* hipStream_t to launch on, NULL = library-owned stream               */
+} amps_recc_cfg_t;
+
+typedef struct amps_recc_timing {
+    uint32_t struct_size;
+    uint32_t launches_front;   /* number of timed launches of the front kernel since last reset           */
+    double   ms_front;         /* summed HIP-event time of the dominant streaming kernel (demod+sync)     */
+    double   ms_resolve;       /* per-channel detection ordering / capture scheduling kernel              */
+    double   ms_decode;        /* burst extract + Manchester + BCH + parse kernel                         */
+    double   ms_carry;         /* inter-push halo copy kernel                                             */
+    double   ms_symbols;       /* symbol-seam work() kernel                                               */
+    uint64_t samples_front;    /* per-channel IQ samples consumed by the timed front launches             */
+} amps_recc_timing_t;
+
+typedef struct amps_recc amps_recc_t; /* opaque; owns device buffers + per-channel stream state */
+
+/* version / introspection */
+int         amps_recc_abi_version(void);
+const char *amps_recc_strerror(int code);
+size_t      amps_recc_burst_size(void);   /* sizeof(amps_recc_burst_t), for binding self-checks */
+
+/* lifetime */
+int  amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg);
+void amps_recc_destroy(amps_recc_t *h);
+int  amps_recc_reset(amps_recc_t *h);     /* back to the just-constructed state of every channel */
+
+/* (i) exact drop-in seam.  One call == one recc_impl::work() call on EVERY channel with
+ * noutput_items = n; syms is [n_channels][ld] bytes (values 0/1).  Bursts published by this call
+ * are copied to bursts_out ([cap][3374] host bytes) with their channel in burst_channel[], sorted
+ * by channel (a channel publishes at most one burst per work() call).  n<1 returns 0 with *nout=0
+ * (lib/recc_impl.cc:99-102); n>AMPS_RECC_MAX_WORK_ITEMS returns -EINVAL (the reference asserts). */
+int amps_recc_push_symbols(amps_recc_t *h, const uint8_t *syms, size_t ld, int n, int mem,
+                           uint8_t *bursts_out, uint32_t *burst_channel, size_t cap, size_t *nout);
+
+/* recc_decode core on a batch of 3374-byte bursts ([nbursts][3374], host or device); out is host. */
+int amps_recc_decode_bursts(amps_recc_t *h, const uint8_t *bursts, size_t nbursts, int mem,
+                            const uint32_t *burst_channel /* may be NULL */, amps_recc_burst_t *out);
+
+/* (ii) fused seam: interleaved fc32 IQ, channel-major: sample i of channel c at iq[2*(c*ld + i)].
+ * Enqueues the fused demod->sync->capture->decode kernels on the handle's stream and returns
+ * without synchronising; results accumulate on the device until amps_recc_drain(). */
+int amps_recc_push_iq(amps_recc_t *h, const float *iq, size_t ld, size_t nsamp, int mem);
+
+/* channelizer seam: one wideband interleaved fc32 stream (fs = M * 30 kHz) -> polyphase
+ * channelizer -> the same fused path on every active channel.  nsamp wideband samples. */
+int amps_recc_push_wideband(amps_recc_t *h, const float *iq, size_t nsamp, int mem);
+
+/* Synchronise the handle's stream and copy out the decoded bursts accumulated since the last
+ * drain, sorted by (channel, position).  -ENOSPC if the device list overflowed max_bursts
+ * (the first max_bursts records are still returned). */
+int amps_recc_drain(amps_recc_t *h, amps_recc_burst_t *out, size_t cap, size_t *nout);
+
+/* test/diagnostic taps (not on the hot path): FM-demod floats and sliced symbol bits of one
+ * channel for the last push_iq() call.  demod/soft/hard are host arrays of length n (may be NULL). */
+int amps_recc_debug_demod(amps_recc_t *h, const float *iq, size_t nsamp, int mem,
+                          float *demod, float *soft, uint8_t *hard);
+
+int amps_recc_get_timing(amps_recc_t *h, amps_recc_timing_t *t, int reset);
+
+/* reply generation of recc_decode: fills the focc_words / fvc_words payloads the
+ * reference would publish for this burst.  Pure host integer code. */
+typedef struct amps_recc_reply {
+    uint8_t  has_focc;  int32_t focc_stream; int32_t focc_nwords; uint8_t focc_word1[28]; uint8_t focc_word2[28];
+    uint8_t  has_fvc;   int32_t fvc_count;   uint8_t fvc_word1[28]; uint64_t fvc_repeat;
+    uint8_t  has_mutes; uint8_t fvc_mute;    uint8_t audio_mute;
+    uint8_t  has_command; char command[48];
+} amps_recc_reply_t;
+int amps_recc_reply_words(const amps_recc_burst_t *burst, amps_recc_reply_t *reply);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMPS_RECC_H */

@@ -1,0 +1,50 @@
+/* amps_recc_numerics.h -- the numeric specification of the fused IQ seam (part of the C ABI contract).
+ *
+ * The float stages of the reference chain are stock GNU Radio blocks (quadrature_demod_cf with
+ * fast_atan2f, grc/recctest.grc:458) whose source is not part of the reference tree.  The fused
+ * MI355X path defines its own FM discriminator arithmetic; it is specified here operation by
+ * operation in IEEE-754 binary32 so that the device kernel and the CPU model under oracle/ produce
+ * bit-identical intermediates (both are compiled with floating-point contraction off and use
+ * explicit fmaf):
+ *
+ *   re = fmaf(xr, pr, xi*pi)          t = x[n] * conj(x[n-1])
+ *   im = fmaf(xi, pr, -(xr*pi))
+ *   ax = |re|  ay = |im|   mx = max(ax,ay)   mn = min(ax,ay)
+ *   q  = mx > 0 ? mn / mx : 0         (IEEE correctly rounded division)
+ *   z  = q*q
+ *   p  = C5; p = fmaf(p,z,C4); ... ; p = fmaf(p,z,C0)        (Horner)
+ *   a  = p*q
+ *   if (ay > ax) a = PI_2 - a
+ *   if (re < 0)  a = PI   - a
+ *   if (im < 0)  a = -a
+ *   d[n] = a                                          |d[n] - atan2(im,re)| <= 4e-6 rad
+ *
+ *   S[n] = (((d[n-sps+1] + d[n-sps+2]) + ...) + d[n])  boxcar over one Manchester symbol,
+ *                                                       summed oldest to newest
+ *   g[n] = S[n] >= 0 ? 1 : 0                           binary_slicer_fb semantics (x >= 0 -> 1)
+ *
+ * Samples before the start of the stream are zero (x = 0 -> d = 0 -> g = 1).
+ */
+#ifndef AMPS_RECC_NUMERICS_H
+#define AMPS_RECC_NUMERICS_H
+
+/* minimax fit of atan(q)/q in z = q*q on [0,1]; max abs error of the binary32 Horner form 1.75e-6 rad */
+#define AMPS_ATAN_C0  0x1.fffd04p-1f
+#define AMPS_ATAN_C1 -0x1.549b12p-2f
+#define AMPS_ATAN_C2  0x1.8c5ed6p-3f
+#define AMPS_ATAN_C3 -0x1.dce1c0p-4f
+#define AMPS_ATAN_C4  0x1.af48f4p-5f
+#define AMPS_ATAN_C5 -0x1.800270p-7f
+#define AMPS_PI_F     0x1.921fb6p+1f
+#define AMPS_PI_2_F   0x1.921fb6p+0f
+
+/* stated tolerance of the FM-demod float intermediate against libm atan2 (radians) */
+#define AMPS_DEMOD_TOL_RAD 1.0e-5f
+
+/* fused-seam geometry shared by kernel, host code and CPU model */
+#define AMPS_TILE_SAMPLES   2048   /* samples per LDS tile                                        */
+#define AMPS_HALO_SAMPLES   2048   /* history recomputed at the head of every chunk / kept per push */
+#define AMPS_WORD_SAMPLES   64     /* samples per packed slicer word                              */
+#define AMPS_DEDUP_SYMBOLS  2      /* trigger hits closer than this many symbols form one run     */
+
+#endif

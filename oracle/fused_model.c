@@ -1,0 +1,158 @@
+/* fused_model.c -- TEST INFRASTRUCTURE ONLY (see amps_oracle.h).
+ *
+ * Scalar CPU model ("port") of the fused MI355X seam: the arithmetic of
+ * include/amps_recc_numerics.h and the detection / capture rules of DESIGN.md section 4,
+ * written as plain sequential loops.  It shares no code with the HIP kernels; the burst decode it
+ * ends in is the reference restatement (orc_decode_burst).  Used (a) to check the kernels bit for
+ * bit, (b) as the `cpu_baseline` "port" leg of bench.py together with the reference chain.
+ */
+#include "amps_oracle.h"
+#include "amps_recc_numerics.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* d = arg(x * conj(p)) per the numeric spec */
+static inline float fm_phase(float xr, float xi, float pr, float pi_)
+{
+    float re = fmaf(xr, pr, xi * pi_);
+    float im = fmaf(xi, pr, -(xr * pi_));
+    float ax = fabsf(re), ay = fabsf(im);
+    float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+    float q = mx > 0.0f ? mn / mx : 0.0f;
+    float z = q * q;
+    float p = AMPS_ATAN_C5;
+    p = fmaf(p, z, AMPS_ATAN_C4);
+    p = fmaf(p, z, AMPS_ATAN_C3);
+    p = fmaf(p, z, AMPS_ATAN_C2);
+    p = fmaf(p, z, AMPS_ATAN_C1);
+    p = fmaf(p, z, AMPS_ATAN_C0);
+    float a = p * q;
+    if (ay > ax) a = AMPS_PI_2_F - a;
+    if (re < 0.0f) a = AMPS_PI_F - a;
+    if (im < 0.0f) a = -a;
+    return a;
+}
+
+void orc_fm_discriminator(const float *iq, size_t n, float *d)
+{
+    float pr = 0.0f, pi_ = 0.0f;
+    for (size_t i = 0; i < n; i++) {
+        d[i] = fm_phase(iq[2 * i], iq[2 * i + 1], pr, pi_);
+        pr = iq[2 * i]; pi_ = iq[2 * i + 1];
+    }
+}
+
+struct orc_fused {
+    uint32_t channel;
+    int      sps;
+    size_t   n_in, cap;       /* samples received so far / allocated                      */
+    size_t   n_done;          /* samples processed so far (multiple of 64)                 */
+    float   *x;               /* 2*cap interleaved IQ                                      */
+    float   *d, *S;           /* demod and boxcar, valid for [0, n_done)                   */
+    uint8_t *g, *M;           /* slicer bits and trigger-hit bits, valid for [0, n_done)   */
+    uint64_t next_allowed;    /* run starts below this are inside an accepted burst        */
+    int      have_pending;
+    uint64_t pending_nc;
+    uint8_t  trig[AMPS_RECC_TRIGGER_SYMS];
+};
+
+orc_fused_t *orc_fused_new(uint32_t channel, int sps)
+{
+    orc_fused_t *f = (orc_fused_t *)calloc(1, sizeof(*f));
+    f->channel = channel; f->sps = sps;
+    orc_trigger(f->trig);
+    return f;
+}
+void orc_fused_free(orc_fused_t *f)
+{
+    if (!f) return;
+    free(f->x); free(f->d); free(f->S); free(f->g); free(f->M); free(f);
+}
+size_t orc_fused_processed(const orc_fused_t *f) { return f->n_done; }
+const float *orc_fused_demod(const orc_fused_t *f) { return f->d; }
+const float *orc_fused_soft(const orc_fused_t *f) { return f->S; }
+const uint8_t *orc_fused_hard(const orc_fused_t *f) { return f->g; }
+
+static void grow(orc_fused_t *f, size_t need)
+{
+    if (need <= f->cap) return;
+    size_t nc = f->cap ? f->cap : 4096;
+    while (nc < need) nc *= 2;
+    f->x = (float *)realloc(f->x, sizeof(float) * 2 * nc);
+    f->d = (float *)realloc(f->d, sizeof(float) * nc);
+    f->S = (float *)realloc(f->S, sizeof(float) * nc);
+    f->g = (uint8_t *)realloc(f->g, nc);
+    f->M = (uint8_t *)realloc(f->M, nc);
+    f->cap = nc;
+}
+
+static inline int gbit(const orc_fused_t *f, int64_t n) { return n < 0 ? 1 : f->g[n]; }
+
+static void capture(orc_fused_t *f, uint64_t nc, amps_recc_burst_t *out)
+{
+    uint8_t burst[AMPS_RECC_CAPTURE_SYMS];
+    for (int i = 0; i < AMPS_RECC_CAPTURE_SYMS; i++) burst[i] = f->g[nc + (uint64_t)f->sps * (uint64_t)(i + 1)];
+    orc_decode_burst(burst, f->channel, nc, out);
+}
+
+size_t orc_fused_push(orc_fused_t *f, const float *iq, size_t n, amps_recc_burst_t *out, size_t cap)
+{
+    const int sps = f->sps, T = AMPS_RECC_TRIGGER_SYMS;
+    const int D = AMPS_DEDUP_SYMBOLS * sps;
+    size_t nout = 0;
+    grow(f, f->n_in + n + 64);
+    memcpy(f->x + 2 * f->n_in, iq, sizeof(float) * 2 * n);
+    f->n_in += n;
+    size_t P = ((f->n_in - f->n_done) / AMPS_WORD_SAMPLES) * AMPS_WORD_SAMPLES;
+    size_t lo = f->n_done, hi = f->n_done + P;
+    /* demod, boxcar, slicer */
+    for (size_t i = lo; i < hi; i++) {
+        float pr = i ? f->x[2 * (i - 1)] : 0.0f, pi_ = i ? f->x[2 * (i - 1) + 1] : 0.0f;
+        f->d[i] = fm_phase(f->x[2 * i], f->x[2 * i + 1], pr, pi_);
+        float s = 0.0f;
+        int first = 1;
+        for (int j = sps - 1; j >= 0; j--) { /* oldest to newest */
+            float v = (int64_t)i - j < 0 ? 0.0f : f->d[i - (size_t)j];
+            if (first) { s = v; first = 0; } else s = s + v;
+        }
+        f->S[i] = s;
+        f->g[i] = s >= 0.0f ? 1 : 0;
+    }
+    /* exact 74-symbol trigger test ending at sample i */
+    for (size_t i = lo; i < hi; i++) {
+        int ok = 1;
+        for (int k = 0; k < T && ok; k++)
+            if (gbit(f, (int64_t)i - (int64_t)sps * (T - 1 - k)) != f->trig[k]) ok = 0;
+        f->M[i] = (uint8_t)ok;
+    }
+    /* run starts located in word w are examined when word w+1 has been processed */
+    int64_t w_lo = (int64_t)(lo / AMPS_WORD_SAMPLES) - 1, w_hi = (int64_t)(hi / AMPS_WORD_SAMPLES) - 1;
+    /* previously accepted burst waiting for its tail */
+    if (f->have_pending && f->pending_nc + (uint64_t)sps * (AMPS_RECC_CAPTURE_SYMS + 1) < hi) {
+        if (nout < cap) capture(f, f->pending_nc, &out[nout++]);
+        f->have_pending = 0;
+    }
+    for (int64_t w = w_lo < 0 ? 0 : w_lo; w < w_hi; w++) {
+        for (int b = 0; b < AMPS_WORD_SAMPLES; b++) {
+            int64_t p = w * AMPS_WORD_SAMPLES + b;
+            if (!f->M[p]) continue;
+            int dup = 0;
+            for (int k = 1; k <= D; k++) if (p - k >= 0 && f->M[p - k]) dup = 1;
+            if (dup) continue;
+            int last = 0;
+            for (int k = 0; k < D; k++) if (f->M[p + k]) last = k; /* p+k < (w+2)*64 since D <= 64 */
+            uint64_t a = (uint64_t)p;
+            if (a < f->next_allowed) continue;
+            uint64_t nc = a + (uint64_t)(last / 2);
+            f->next_allowed = nc + (uint64_t)sps * (AMPS_RECC_CAPTURE_SYMS + AMPS_RECC_TRIGGER_SYMS);
+            if (nc + (uint64_t)sps * (AMPS_RECC_CAPTURE_SYMS + 1) < hi) {
+                if (nout < cap) capture(f, nc, &out[nout++]);
+            } else {
+                f->have_pending = 1; f->pending_nc = nc;
+            }
+        }
+    }
+    f->n_done = hi;
+    return nout;
+}
