@@ -133,6 +133,22 @@ void collect_spans(amps_recc *h)   // stream must be synchronised
     h->spans.clear();
 }
 
+// AMPS_RECC_DEBUG_SYNC=1: synchronise after every launch and say which kernel ran (fault isolation)
+bool debug_sync_enabled()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = std::getenv("AMPS_RECC_DEBUG_SYNC"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+int debug_sync(amps_recc *h, const char *what)
+{
+    if (!debug_sync_enabled()) return 0;
+    std::fprintf(stderr, "amps_recc[debug]: %s ...", what); std::fflush(stderr);
+    hipError_t e = hipStreamSynchronize(h->stream);
+    std::fprintf(stderr, " %s\n", e == hipSuccess ? "ok" : hipGetErrorString(e)); std::fflush(stderr);
+    return e == hipSuccess ? 0 : -EIO;
+}
+
 uint32_t next_pow2(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return (uint32_t)p; }
 
 int reset_state(amps_recc *h)
@@ -205,9 +221,13 @@ int run_iq_device(amps_recc *h, const float2 *iq, uint64_t ld, uint32_t nsamp)
         fa.det = h->det; fa.detcount = h->detcount; fa.max_chunks = h->max_chunks; fa.det_cap = h->det_cap;
         fa.status = h->status; fa.dbg_d = h->dbg_d; fa.dbg_S = h->dbg_S; fa.dbg_channel = 0;
         SpanGuard g(h, T_FRONT, P);
-        int rc = dispatch_front(h->sps, fa, dim3(nchunks, h->C), s);
+        if (debug_sync_enabled())
+            std::fprintf(stderr, "amps_recc[debug]: front grid=(%u,%u) P=%u avail=%u r_prev=%u tpc=%u ld=%llu n_done=%llu ring_words=%u max_chunks=%u det_cap=%u\n",
+                         nchunks, h->C, P, avail, h->r_prev, h->tiles_per_chunk, (unsigned long long)ld, (unsigned long long)h->n_done, h->ring_words, h->max_chunks, h->det_cap);
+        int rc = dispatch_front(h->sps, fa, dim3((nchunks + 3) / 4, h->C), s);
         if (rc) return rc;
     }
+    if (int rc = debug_sync(h, "front")) return rc;
     {
         CarryArgs ca{};
         ca.block = iq; ca.carry_in = h->carry[h->carry_cur]; ca.carry_out = h->carry[h->carry_cur ^ 1];
@@ -215,6 +235,7 @@ int run_iq_device(amps_recc *h, const float2 *iq, uint64_t ld, uint32_t nsamp)
         SpanGuard g(h, T_CARRY);
         hipLaunchKernelGGL(recc_carry_kernel, dim3((HALO + r_new + 255) / 256, h->C), dim3(256), 0, s, ca);
     }
+    if (int rc = debug_sync(h, "carry")) return rc;
     if (P) {
         HIP_TRY(hipMemsetAsync(h->capq_count, 0, sizeof(uint32_t), s));
         ResolveArgs ra{};
@@ -226,6 +247,7 @@ int run_iq_device(amps_recc *h, const float2 *iq, uint64_t ld, uint32_t nsamp)
             SpanGuard g(h, T_RESOLVE);
             hipLaunchKernelGGL(recc_resolve_kernel, dim3(h->C), dim3(64), 0, s, ra);
         }
+        if (int rc = debug_sync(h, "resolve")) return rc;
         CaptureArgs ca{};
         ca.capq = h->capq; ca.capq_count = h->capq_count; ca.capq_cap = h->cfg.max_bursts; ca.sps = h->sps;
         ca.gring = h->gring; ca.ring_mask = h->ring_words - 1; ca.ring_words = h->ring_words;
@@ -235,6 +257,7 @@ int run_iq_device(amps_recc *h, const float2 *iq, uint64_t ld, uint32_t nsamp)
             uint32_t grid = std::min<uint32_t>(h->cfg.max_bursts, 2048u);
             hipLaunchKernelGGL(recc_capture_kernel, dim3(grid), dim3(64), 0, s, ca);
         }
+        if (int rc = debug_sync(h, "capture")) return rc;
     }
     HIP_TRY(hipGetLastError());
     h->n_done += P;
@@ -310,8 +333,8 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
         const uint64_t maxs = cfg->max_samples_per_push;
         h->ring_words = next_pow2(maxs + (uint64_t)h->sps * (AMPS_RECC_CAPTURE_SYMS + 2 * AMPS_RECC_TRIGGER_SYMS + 64) + 2 * TILE) / 64;
         const uint64_t max_tiles = (maxs + 63 + TILE - 1) / TILE + 1;
-        uint64_t tpc = (max_tiles * C) / 4096;              // aim for >= ~4096 workgroups per launch
-        tpc = std::max<uint64_t>(4, std::min<uint64_t>(32, tpc));
+        uint64_t tpc = (max_tiles * C) / 8192;              // aim for >= ~8192 wave-chunks per launch (256 CUs x 16+ waves)
+        tpc = std::max<uint64_t>(32, std::min<uint64_t>(128, tpc));   // halo = 2 tiles per chunk -> 1.6..6 % re-read
         h->tiles_per_chunk = (uint32_t)tpc;
         h->max_chunks = (uint32_t)((max_tiles + tpc - 1) / tpc);
         h->det_cap = (uint32_t)(tpc * TILE / ((uint64_t)AMPS_RECC_TRIGGER_SYMS * h->sps) + 4);

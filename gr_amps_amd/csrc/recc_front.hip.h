@@ -13,22 +13,26 @@
 //   recc_impl::work trigger memmem      lib/recc_impl.cc:115-119  -> exact 74-symbol match, bit-parallel
 //                                                                    over 64 sample phases per lane
 //
-// Mapping to the hardware
-//   * grid = (chunks, channels); a 256-thread workgroup (4 waves) walks one chunk of one channel in
-//     2048-sample tiles, so a launch has chunks*channels >> 256 workgroups and every CU streams.
-//   * HBM reads: each wave owns a 512-sample strip of the tile and issues eight 512-byte coalesced
-//     `global_load_dwordx2` per tile (one fc32 sample per lane), all eight for tile k+1 in flight
-//     while tile k is processed (register double buffer) -- IQ is read exactly once, plus one halo
-//     tile per chunk (3 % at 32 tiles/chunk).
-//   * LDS: demod floats are staged in a padded (stride 9/8) array so the contiguous 17-float window
-//     every thread needs for 8 boxcar outputs is bank-conflict free; slicer bits live in a 4-tile
-//     LDS bit ring that is the sliding window of the trigger correlator (730 bits of history).
+// Mapping to the hardware ("wave-streams")
+//   * every 64-lane wavefront is an independent stream processor: it owns one time-chunk of one
+//     channel and walks it in 512-sample tiles.  Nothing is shared between the 4 waves of a
+//     workgroup, so there is no s_barrier anywhere; a launch has chunks*channels >> 256*16 waves.
+//   * HBM reads: four coalesced 1 KiB `global_load_dwordx4` per tile (two fc32 samples per lane) on
+//     a wave-uniform fast path with no per-lane branches; the loads of tile k+1 are in flight while
+//     tile k is processed (register double buffer).  IQ is read exactly once, plus a 1024-sample
+//     halo per chunk (2-6 %).  Only tiles that touch the inter-push carry or the end of the data take
+//     the generic (branchy) path.
+//   * the x[n-1] neighbour comes from the lane's own float4 (odd samples) or one `__shfl_up` (even).
+//   * LDS (private to the wave): demod floats go through a padded (stride 9/8) 2-tile ring so the
+//     contiguous window each lane needs for 8 boxcar outputs is bank-conflict free; slicer bits live
+//     in a 2048-bit ring that is the sliding window of the trigger correlator (730 bits of history).
 //   * the correlator is bit-parallel: a lane tests 64 consecutive sample phases against one tap of
-//     the 74-symbol pattern with one funnel shift + xnor; 8 lanes share a 64-phase word and combine
-//     with three `__shfl_xor` AND steps.  Hits are rare, so the emit path is a wave-uniform branch.
+//     the 74-symbol pattern with one funnel shift + xnor.  8 lanes share a 64-phase word; a 16-tap
+//     prefilter on the word-sync symbols (2 taps per lane, three `__shfl_xor` AND steps, one ballot)
+//     rejects noise with probability 1-2^-16 per phase; only then are all 74 taps evaluated.
 //   * HBM writes: 1 bit per sample of slicer output (1.6 % of the read volume) into a per-channel
 //     ring that the capture/decode kernel reads, plus 8 bytes per trigger hit.
-// No MFMA: there is no dense contraction on this path; it is HBM-bound (~45 VALU ops per 8-byte sample).
+// No MFMA: there is no dense contraction on this path; it is HBM-bound.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -37,10 +41,11 @@
 
 namespace amps {
 
-constexpr int TILE = AMPS_TILE_SAMPLES;      // 2048
-constexpr int HALO = AMPS_HALO_SAMPLES;      // 2048
+constexpr int TILE = AMPS_TILE_SAMPLES;      // 512 samples per wave tile
+constexpr int HALO = AMPS_HALO_SAMPLES;      // 1024 = 2 tiles of history per chunk / push
 constexpr int CARRY_CAP = HALO + 64;         // samples kept per channel between pushes
 constexpr int TRIG = AMPS_RECC_TRIGGER_SYMS; // 74
+static_assert(HALO == 2 * TILE, "halo is two wave tiles");
 
 // trigger symbols, lib/recc_impl.cc:76 Manchester coded (bit i of the pair = symbol i)
 // "1010101010101010101010101011100010010" -> symbols 01 10 01 10 ...
@@ -67,7 +72,7 @@ struct FrontArgs {
     uint32_t r_prev;         // leftover samples of the previous push held in carry after the halo
     uint32_t avail;          // r_prev + nsamp
     uint32_t P;              // samples processed by this launch (multiple of 64)
-    uint32_t tiles_per_chunk;
+    uint32_t tiles_per_chunk;// wave tiles per wave chunk
     uint64_t n_done;         // absolute index of rel sample 0 (multiple of 64)
     uint64_t *gring;         // [C][ring_words] slicer bits, word = abs_sample/64 & ring_mask
     uint32_t ring_mask;      // ring_words - 1
@@ -81,6 +86,8 @@ struct FrontArgs {
     float    *dbg_S;
     uint32_t dbg_channel;
 };
+
+typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));  // two fc32 samples, 8-byte aligned
 
 __device__ __forceinline__ float fm_phase(float xr, float xi, float pr, float pi_)
 {
@@ -103,138 +110,160 @@ __device__ __forceinline__ float fm_phase(float xr, float xi, float pr, float pi
     return a;
 }
 
-__device__ __forceinline__ int didx(int n) { return n + (n >> 3); } // padded LDS index of tile-local sample n
+constexpr int DRING = 2 * TILE;                                   // demod ring: 2 tiles
+__device__ __forceinline__ int didx(int n) { return n + (n >> 3); } // padded LDS index, n in [0, DRING)
 
 template <int SPS>
 __global__ __launch_bounds__(256) void recc_front_kernel(FrontArgs a)
 {
     static_assert(SPS >= 2 && SPS <= 16, "samples per symbol");
-    constexpr int H = SPS - 1;               // boxcar history
+    constexpr int H = SPS - 1;                  // boxcar history
     constexpr int D = AMPS_DEDUP_SYMBOLS * SPS; // dedup / run window in samples (<= 32)
-    __shared__ float    s_d[TILE + TILE / 8];       // padded demod floats of the current tile
-    __shared__ float    s_dhist[2][16];             // last 16 demod floats of the previous tile
-    __shared__ uint64_t s_g[4 * TILE / 64];         // slicer bit ring, 4 tiles
-    __shared__ uint64_t s_m[4 * TILE / 64];         // trigger-hit bit ring, 4 tiles
-    __shared__ uint32_t s_ndet;
+    constexpr int GW = 4 * TILE / 64;           // words in the per-wave bit rings (4 tiles)
+    __shared__ float    s_d_all[4][DRING + DRING / 8];
+    __shared__ uint64_t s_g_all[4][GW];
+    __shared__ uint64_t s_m_all[4][GW];
 
-    const int c = blockIdx.y, chunk = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.y;
+    const int chunk = blockIdx.x * 4 + wv;
     const int64_t chunk_start = (int64_t)chunk * a.tiles_per_chunk * TILE;   // rel
-    if (chunk_start >= (int64_t)a.P) return;
+    if (chunk_start >= (int64_t)a.P) return;     // whole wave leaves; no barriers are used below
     int64_t chunk_len = (int64_t)a.P - chunk_start;
     if (chunk_len > (int64_t)a.tiles_per_chunk * TILE) chunk_len = (int64_t)a.tiles_per_chunk * TILE;
     const int K = (int)((chunk_len + TILE - 1) / TILE);  // real tiles in this chunk
     const int64_t words_end = (int64_t)a.P / 64;          // rel word index limit of this launch
 
+    float *s_d = s_d_all[wv];
+    uint64_t *s_g = s_g_all[wv];
+    uint64_t *s_m = s_m_all[wv];
     const float2 *blk = a.block + (uint64_t)c * a.ld;
     const float2 *car = a.carry + (uint64_t)c * CARRY_CAP;
     const int r_prev = (int)a.r_prev, avail = (int)a.avail;
 
-    auto fetch = [&](int64_t i) -> float2 {   // virtual stream: carry then block; zero beyond the data
-        if (i >= avail) return make_float2(0.f, 0.f);
+    auto fetch = [&](int64_t i) -> float2 {   // generic path: carry then block; zero outside the data
+        if (i >= avail || i < -(int64_t)HALO) return make_float2(0.f, 0.f);
         const float2 *p = (i < r_prev) ? (car + (HALO + i)) : (blk + (i - r_prev));
         return *p;
     };
-
-    if (tid == 0) s_ndet = 0;
-    for (int i = tid; i < 4 * TILE / 64; i += 256) { s_g[i] = ~0ull; s_m[i] = 0; }
-    if (tid < 32) ((float *)s_dhist)[tid] = 0.f;
-
-    float2 cur[8], nxt[8], cur_edge, nxt_edge;
-    {
-        const int64_t t0 = chunk_start - TILE + 512 * wv;
+    // one 512-sample tile: r[q] = samples (s0 + 128q + 2*lane, +1)
+    auto load_tile = [&](float4 (&r)[4], int64_t s0) {
+        if (s0 >= r_prev && s0 + TILE <= avail) {          // wave-uniform: entirely inside the new block
+            const f4a8 *p = (const f4a8 *)(blk + (s0 - r_prev)) + lane;
 #pragma unroll
-        for (int j = 0; j < 8; j++) cur[j] = fetch(t0 + 64 * j + lane);
-        cur_edge = fetch(t0 - 1);
-    }
-    __syncthreads();
-
-    // k = 0 is the halo tile [chunk_start-2048, chunk_start): recomputed, never stored or emitted
-    for (int k = 0; k <= K; k++) {
-        const int64_t t0 = chunk_start + (int64_t)(k - 1) * TILE;  // rel start of this tile
-        // ---- P1: prefetch next tile, demodulate this one into LDS ----
-        if (k < K) {
-            const int64_t n0 = t0 + TILE + 512 * wv;
+            for (int q = 0; q < 4; q++) { f4a8 v = p[64 * q]; r[q] = make_float4(v.x, v.y, v.z, v.w); }
+        } else {
 #pragma unroll
-            for (int j = 0; j < 8; j++) nxt[j] = fetch(n0 + 64 * j + lane);
-            nxt_edge = fetch(n0 - 1);
+            for (int q = 0; q < 4; q++) {
+                float2 u = fetch(s0 + 128 * q + 2 * lane), w = fetch(s0 + 128 * q + 2 * lane + 1);
+                r[q] = make_float4(u.x, u.y, w.x, w.y);
+            }
         }
+    };
+
+    if (lane < GW) { s_g[lane] = ~0ull; s_m[lane] = 0; }
+    for (int i = lane; i < DRING + DRING / 8; i += 64) s_d[i] = 0.f;
+
+    float4 cur[4], nxt[4];
+    float last_x = 0.f, last_y = 0.f;            // last sample of the previous tile (wave-uniform)
+    uint32_t ndet = 0;                           // hits appended by this wave (wave-uniform)
+    load_tile(cur, chunk_start - HALO);
+
+    // k = -2, -1 are the halo tiles [chunk_start-1024, chunk_start): recomputed, never stored or emitted
+    for (int k = -2; k < K; k++) {
+        const int64_t t0 = chunk_start + (int64_t)k * TILE;   // rel start of this tile
+        const int slot = (k + 2) & 3;                          // bit-ring slot of this tile
+        const int dbase = ((k + 2) & 1) * TILE;                // demod-ring base of this tile
+        // ---- P1: prefetch the next tile, demodulate this one into LDS ----
+        if (k + 1 < K) load_tile(nxt, t0 + TILE);
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            float pr = __shfl_up(cur[j].x, 1), pi_ = __shfl_up(cur[j].y, 1);
+        for (int q = 0; q < 4; q++) {
+            float pr = __shfl_up(cur[q].z, 1), pi_ = __shfl_up(cur[q].w, 1);
             float er, ei;
-            if (j == 0) { er = cur_edge.x; ei = cur_edge.y; }
-            else { er = __shfl(cur[j - 1].x, 63); ei = __shfl(cur[j - 1].y, 63); }
+            if (q == 0) { er = last_x; ei = last_y; }
+            else { er = __shfl(cur[q - 1].z, 63); ei = __shfl(cur[q - 1].w, 63); }
             if (lane == 0) { pr = er; pi_ = ei; }
-            s_d[didx(512 * wv + 64 * j + lane)] = fm_phase(cur[j].x, cur[j].y, pr, pi_);
+            const int n = dbase + 128 * q + 2 * lane;
+            s_d[didx(n)] = fm_phase(cur[q].x, cur[q].y, pr, pi_);
+            s_d[didx(n + 1)] = fm_phase(cur[q].z, cur[q].w, cur[q].x, cur[q].y);
         }
-        __syncthreads();
-        // ---- P2: boxcar over one symbol, slice, pack 8 bits per thread ----
+        last_x = __shfl(cur[3].z, 63);
+        last_y = __shfl(cur[3].w, 63);
+        __builtin_amdgcn_wave_barrier();
+        // ---- P2: boxcar over one symbol (aligned pair sums), slice, pack 8 bits per lane ----
         {
             float v[H + 8];
-            const int base = 8 * tid - H;
 #pragma unroll
-            for (int m = 0; m < H + 8; m++) {
-                int n = base + m;
-                v[m] = n >= 0 ? s_d[didx(n)] : s_dhist[k & 1][16 + n];
-            }
+            for (int m = 0; m < H + 8; m++) v[m] = s_d[didx((dbase + 8 * lane - H + m) & (DRING - 1))];
             unsigned byte = 0;
-            const bool tap = a.dbg_d && (uint32_t)c == a.dbg_channel && k > 0;
+            const bool tap = a.dbg_d && (uint32_t)c == a.dbg_channel && k >= 0;
 #pragma unroll
             for (int q = 0; q < 8; q++) {
-                float s = v[q];
+                // window v[q .. q+H]; v[j] has absolute parity (j + H) & 1 because 8*lane is even
+                const int lead = (q + H) & 1;                 // window starts on an odd sample
+                const int j0 = q + lead;
+                const int npairs = (q + H - j0 + 1) / 2;
+                const int trail = (q + H - j0 + 1) & 1;       // window ends on an even sample
+                float s = lead ? v[q] : (v[j0] + v[j0 + 1]);
 #pragma unroll
-                for (int r = 1; r < SPS; r++) s = s + v[q + r];  // oldest -> newest
+                for (int u = lead ? 0 : 1; u < npairs; u++) s = s + (v[j0 + 2 * u] + v[j0 + 2 * u + 1]);
+                if (trail) s = s + v[q + H];
                 byte |= (s >= 0.0f ? 1u : 0u) << q;
                 if (tap) {
-                    int64_t rel = t0 + 8 * tid + q;
+                    int64_t rel = t0 + 8 * lane + q;
                     if (rel < (int64_t)a.P) { a.dbg_d[rel] = v[q + H]; a.dbg_S[rel] = s; }
                 }
             }
-            ((uint8_t *)s_g)[(k & 3) * (TILE / 8) + tid] = (uint8_t)byte;
-            if (tid >= 254) {
-#pragma unroll
-                for (int q = 0; q < 8; q++) s_dhist[(k + 1) & 1][(tid - 254) * 8 + q] = v[H + q];
-            }
+            ((uint8_t *)s_g)[slot * (TILE / 8) + lane] = (uint8_t)byte;
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
         // ---- P3a: bit-parallel exact match of the 74-symbol trigger; publish slicer words ----
+        const int wl = lane & 7;             // word within the tile (0..7)
+        const int part = lane >> 3;          // 8 lanes share a word
         {
-            const int wl = wv * 8 + (lane & 7);   // word within tile (0..31)
-            const int part = lane >> 3;           // 8 lanes share a word, each takes every 8th tap
-            uint64_t acc = ~0ull;
-            const int bitbase = (k & 3) * TILE + 64 * wl;
-            for (int i = part; i < TRIG; i += 8) {
+            const int bitbase = slot * TILE + 64 * wl;
+            auto tap_word = [&](int i) -> uint64_t {   // 64 phases of tap i, 1 = symbol matches
                 int B = (bitbase - SPS * (TRIG - 1 - i)) & (4 * TILE - 1);
                 int qw = B >> 6, sh = B & 63;
-                uint64_t lo = s_g[qw], hi = s_g[(qw + 1) & (4 * TILE / 64 - 1)];
+                uint64_t lo = s_g[qw], hi = s_g[(qw + 1) & (GW - 1)];
                 uint64_t val = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
                 uint64_t t = (i < 64 ? (TRIG_LO >> i) : (TRIG_HI >> (i - 64))) & 1ull;
-                acc &= t ? val : ~val;
+                return t ? val : ~val;
+            };
+            auto and_parts = [&](uint64_t x) -> uint64_t {
+                x &= __shfl_xor(x, 8);
+                x &= __shfl_xor(x, 16);
+                x &= __shfl_xor(x, 32);
+                return x;
+            };
+            // prefilter: the last 16 symbols (all inside the word-sync part), 2 taps per lane
+            uint64_t acc = and_parts(tap_word(TRIG - 1 - part) & tap_word(TRIG - 9 - part));
+            if (__ballot(acc != 0)) {        // rare: evaluate all 74 taps
+                acc = ~0ull;
+                for (int i = part; i < TRIG; i += 8) acc &= tap_word(i);
+                acc = and_parts(acc);
             }
-            acc &= __shfl_xor(acc, 8);
-            acc &= __shfl_xor(acc, 16);
-            acc &= __shfl_xor(acc, 32);
             if (part == 0) {
-                s_m[(k & 3) * (TILE / 64) + wl] = acc;
+                s_m[slot * (TILE / 64) + wl] = acc;
                 const int64_t relw = t0 / 64 + wl;      // rel word index (t0 is a multiple of 64)
-                if (k > 0 && relw < words_end) {
+                if (k >= 0 && relw < words_end) {
                     uint64_t absw = a.n_done / 64 + (uint64_t)relw;
-                    a.gring[(uint64_t)c * a.ring_words + (absw & a.ring_mask)] = s_g[(k & 3) * (TILE / 64) + wl];
+                    a.gring[(uint64_t)c * a.ring_words + (absw & a.ring_mask)] = s_g[slot * (TILE / 64) + wl];
                 }
             }
         }
-        __syncthreads();
-        // ---- P3b: emit run starts located in [previous tile word 31, this tile words 0..30] ----
-        if (k > 0 && wv == 0) {
+        __builtin_amdgcn_wave_barrier();
+        // ---- P3b: emit run starts located in [previous tile word 7, this tile words 0..6] ----
+        if (k >= 0) {
             uint64_t starts = 0, mcur = 0, mnext = 0;
             int64_t relw = 0;
-            if (lane < 32) {
-                const int ring_w = ((k & 3) * (TILE / 64) + lane - 1) & (4 * TILE / 64 - 1); // word examined
+            if (lane < 8) {
+                const int ring_w = (slot * (TILE / 64) + lane - 1) & (GW - 1);   // word examined
                 relw = t0 / 64 + lane - 1;
-                const uint64_t mprev = s_m[(ring_w - 1) & (4 * TILE / 64 - 1)];
+                const uint64_t mprev = s_m[(ring_w - 1) & (GW - 1)];
                 mcur = s_m[ring_w];
-                mnext = s_m[(ring_w + 1) & (4 * TILE / 64 - 1)];
+                mnext = s_m[(ring_w + 1) & (GW - 1)];
                 uint64_t smear = 0;
 #pragma unroll
                 for (int s = 1; s <= D; s++) smear |= (mcur << s) | (mprev >> (64 - s));
@@ -243,40 +272,33 @@ __global__ __launch_bounds__(256) void recc_front_kernel(FrontArgs a)
                 const int64_t absw = (int64_t)(a.n_done / 64) + relw;
                 if (absw < 0 || relw + 1 >= words_end) starts = 0;
             }
-            if (__ballot(starts != 0)) {              // rare: wave-uniform slow path, ordered append
-                int cnt = __popcll(starts);
-                int incl = cnt;
-#pragma unroll
-                for (int s = 1; s < 64; s <<= 1) { int o = __shfl_up(incl, s); if (lane >= s) incl += o; }
-                int excl = incl - cnt;
-                const uint32_t base = s_ndet;
-                uint64_t *dst = a.det + ((uint64_t)c * a.max_chunks + chunk) * a.det_cap;
-                int slot = (int)base + excl;
-                while (starts) {
-                    int p = __ffsll((unsigned long long)starts) - 1;
-                    starts &= starts - 1;
-                    uint64_t win = (mcur >> p) | (p ? (mnext << (64 - p)) : 0ull);
-                    win &= (1ull << D) - 1ull;
-                    int last = 63 - __clzll((long long)win);
-                    uint64_t absn = a.n_done + (uint64_t)(relw * 64 + p);
-                    if (slot < (int)a.det_cap) dst[slot] = (absn << 8) | (uint64_t)last;
-                    else atomicOr(a.status, 1u);
-                    slot++;
+            uint64_t who = __ballot(starts != 0);
+            while (who) {                                 // rare: ordered append, lane by lane
+                const int l = __ffsll((unsigned long long)who) - 1;
+                who &= who - 1;
+                const int cnt = __popcll(__shfl(starts, l));
+                if (lane == l) {
+                    uint64_t *dst = a.det + ((uint64_t)c * a.max_chunks + chunk) * a.det_cap;
+                    uint32_t slot_i = ndet;
+                    while (starts) {
+                        int p = __ffsll((unsigned long long)starts) - 1;
+                        starts &= starts - 1;
+                        uint64_t win = (mcur >> p) | (p ? (mnext << (64 - p)) : 0ull);
+                        win &= (1ull << D) - 1ull;
+                        int last = 63 - __clzll((long long)win);
+                        uint64_t absn = a.n_done + (uint64_t)(relw * 64 + p);
+                        if (slot_i < a.det_cap) dst[slot_i] = (absn << 8) | (uint64_t)last;
+                        else atomicOr(a.status, 1u);
+                        slot_i++;
+                    }
                 }
-                int total = __shfl(incl, 63);
-                if (lane == 0) s_ndet = base + (uint32_t)total;
+                ndet += (uint32_t)cnt;
             }
         }
 #pragma unroll
-        for (int j = 0; j < 8; j++) cur[j] = nxt[j];
-        cur_edge = nxt_edge;
-        // no barrier needed here: the next P1 only writes s_d (last read before the P2/P3 barriers)
+        for (int q = 0; q < 4; q++) cur[q] = nxt[q];
     }
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t n = s_ndet < a.det_cap ? s_ndet : a.det_cap;
-        a.detcount[(uint64_t)c * a.max_chunks + chunk] = n;
-    }
+    if (lane == 0) a.detcount[(uint64_t)c * a.max_chunks + chunk] = ndet < a.det_cap ? ndet : a.det_cap;
 }
 
 // carry[c][k] = V(P - HALO + k) for k in [0, HALO + r_new): the halo the next push recomputes from

@@ -1,0 +1,20 @@
+// gr::amps::recc_fused -- NEW block type (not in the reference): replaces the whole sub-chain
+//   quadrature_demod_cf -> clock_recovery_mm_ff -> binary_slicer_fb -> amps_recc   (grc/ampsbs.grc:775,1752,1713,497)
+// with the fused MI355X kernel.  Input: one gr_complex stream at samples_per_symbol * 20 kHz
+// (200 ksps for the flow graphs as wired); output: the same "bursts" message port as gr::amps::recc,
+// so amps_recc_decode connects to it unchanged.  It additionally publishes the already decoded
+// record on port "records" (blob of amps_recc_burst_t).
+#pragma once
+#include <amps/api.h>
+
+namespace gr {
+namespace amps {
+
+class AMPS_API recc_fused : virtual public gr::sync_block {
+public:
+    typedef AMPS_SPTR<recc_fused> sptr;
+    static sptr make(int samples_per_symbol = 10);
+};
+
+} // namespace amps
+} // namespace gr

@@ -19,8 +19,11 @@
  *   if (im < 0)  a = -a
  *   d[n] = a                                          |d[n] - atan2(im,re)| <= 4e-6 rad
  *
- *   S[n] = (((d[n-sps+1] + d[n-sps+2]) + ...) + d[n])  boxcar over one Manchester symbol,
- *                                                       summed oldest to newest
+ *   boxcar over one Manchester symbol (sps samples ending at n), summed oldest to newest over
+ *   aligned pair sums  p[m] = d[2m] + d[2m+1]  (m = absolute sample index / 2):
+ *     the window [n-sps+1, n] is cut into: a leading single d[n-sps+1] if that index is odd,
+ *     then every aligned pair inside the window, then a trailing single d[n] if n is even;
+ *     S[n] = ((first + second) + third) + ...   in that order
  *   g[n] = S[n] >= 0 ? 1 : 0                           binary_slicer_fb semantics (x >= 0 -> 1)
  *
  * Samples before the start of the stream are zero (x = 0 -> d = 0 -> g = 1).
@@ -42,8 +45,8 @@
 #define AMPS_DEMOD_TOL_RAD 1.0e-5f
 
 /* fused-seam geometry shared by kernel, host code and CPU model */
-#define AMPS_TILE_SAMPLES   2048   /* samples per LDS tile                                        */
-#define AMPS_HALO_SAMPLES   2048   /* history recomputed at the head of every chunk / kept per push */
+#define AMPS_TILE_SAMPLES   512    /* samples per wavefront tile (64 lanes x 8 samples)            */
+#define AMPS_HALO_SAMPLES   1024   /* history recomputed at the head of every chunk / kept per push */
 #define AMPS_WORD_SAMPLES   64     /* samples per packed slicer word                              */
 #define AMPS_DEDUP_SYMBOLS  2      /* trigger hits closer than this many symbols form one run     */
 

@@ -110,10 +110,20 @@ size_t orc_fused_push(orc_fused_t *f, const float *iq, size_t n, amps_recc_burst
     for (size_t i = lo; i < hi; i++) {
         float pr = i ? f->x[2 * (i - 1)] : 0.0f, pi_ = i ? f->x[2 * (i - 1) + 1] : 0.0f;
         f->d[i] = fm_phase(f->x[2 * i], f->x[2 * i + 1], pr, pi_);
+        /* boxcar per the numeric spec: aligned pair sums, oldest to newest */
         float s = 0.0f;
         int first = 1;
-        for (int j = sps - 1; j >= 0; j--) { /* oldest to newest */
-            float v = (int64_t)i - j < 0 ? 0.0f : f->d[i - (size_t)j];
+        int64_t lo_n = (int64_t)i - (sps - 1), hi_n = (int64_t)i, m = lo_n;
+        while (m <= hi_n) {
+            float v;
+            if ((m & 1) == 0 && m + 1 <= hi_n) {            /* aligned pair (m even; negative m: both zero) */
+                float a0 = m < 0 ? 0.0f : f->d[m], a1 = m + 1 < 0 ? 0.0f : f->d[m + 1];
+                v = a0 + a1;
+                m += 2;
+            } else {
+                v = m < 0 ? 0.0f : f->d[m];
+                m += 1;
+            }
             if (first) { s = v; first = 0; } else s = s + v;
         }
         f->S[i] = s;

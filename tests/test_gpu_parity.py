@@ -277,7 +277,7 @@ def test_full_size_roundtrip_properties(gpu):
     C, N, base = 832, 1 << 17, 8
     iq, truth = _channels(base, N, 600, nb=3)
     dev = torch.from_numpy(iq).to("cuda:0").repeat(C // base, 1).contiguous()
-    with capi.Recc(n_channels=C, sps=10, max_samples=N, max_bursts=4 * C) as r:
+    with capi.Recc(n_channels=C, sps=10, max_samples=N, max_bursts=8 * C) as r:
         r.push_iq(dev)
         r.push_iq(dev)          # same block again: stream continues, bursts found again
         got = r.drain()
