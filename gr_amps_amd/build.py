@@ -9,7 +9,8 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libamps_recc.so")
 # -ffp-contract=off: the float stage is specified operation by operation (include/amps_recc_numerics.h)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-               "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+               "-fno-fast-math", "-fno-slp-vectorize",  # SLP packs the demod into v_pk_* + v_mov shuffles: -10 % (measured)
+               "-Wall", "-Wno-unused-function"]
 
 
 def _sources():

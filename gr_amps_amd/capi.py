@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libamps_recc.so")
+LIB_PATH = os.environ.get("AMPS_RECC_LIB") or os.path.join(_HERE, "libamps_recc.so")  # env override: A/B builds only
 
 CAPTURE = 3374
 MAX_WORK_ITEMS = 61439
@@ -237,7 +237,9 @@ class Recc:
 
     def drain(self, cap=None):
         cap = cap or self.max_bursts
-        out = np.zeros(cap, BURST_DTYPE)
+        out = getattr(self, "_drain_buf", None)
+        if out is None or out.shape[0] < cap:
+            out = self._drain_buf = np.empty(cap, BURST_DTYPE)   # reused: a drain should not cost a 3 MB memset
         nout = C.c_size_t(0)
         rc = load().amps_recc_drain(self._h, _hostptr(out), cap, C.byref(nout))
         if rc:

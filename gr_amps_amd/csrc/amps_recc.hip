@@ -54,7 +54,7 @@ struct amps_recc {
     uint32_t r_prev = 0;
     uint64_t *gring = nullptr;
     uint32_t ring_words = 0;
-    uint32_t tiles_per_chunk = 0, max_chunks = 0, det_cap = 0;
+    uint32_t max_waves = 0, max_chunks = 0, det_cap = 0;   // front-launch geometry bounds (see run_iq_device)
     uint64_t *det = nullptr;
     uint32_t *detcount = nullptr;
     uint64_t *next_allowed = nullptr, *pending = nullptr;
@@ -63,6 +63,8 @@ struct amps_recc {
     amps_recc_burst_t *records = nullptr;
     uint32_t *nrecords = nullptr;
     uint32_t *status = nullptr;
+    amps_recc_burst_t *rec_host = nullptr;   // pinned staging for drain()
+    uint32_t *hdr_host = nullptr;             // pinned {nrecords, status}
     float2 *stage_iq = nullptr;       // device staging for host-resident IQ
     size_t stage_iq_samples = 0;
 
@@ -149,6 +151,8 @@ int debug_sync(amps_recc *h, const char *what)
     return e == hipSuccess ? 0 : -EIO;
 }
 
+constexpr uint64_t MIN_SPAN = 16;   // tiles per wave at least: bounds the 2-tile halo overhead to 12.5 % on tiny pushes
+
 uint32_t next_pow2(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return (uint32_t)p; }
 
 int reset_state(amps_recc *h)
@@ -178,9 +182,43 @@ int reset_state(amps_recc *h)
     return 0;
 }
 
+int front_depth()   // tiles in flight per wave; AMPS_RECC_DEPTH overrides for experiments
+{
+    static int v = 0;
+    if (!v) { const char *e = std::getenv("AMPS_RECC_DEPTH"); v = e ? std::atoi(e) : 1; if (v < 1 || v > 3) v = 1; }   // measured: 1 -> 0.347 ms, 2 -> 0.370, 3 -> 0.452 (832 ch x 2^18)
+    return v;
+}
+template <int SPS> int front_blocks_per_cu()
+{
+    int n = 0;
+    hipError_t e;
+    switch (front_depth()) {
+    case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, recc_front_kernel<SPS, 2>, 256, 0); break;
+    case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, recc_front_kernel<SPS, 3>, 256, 0); break;
+    default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, recc_front_kernel<SPS, 1>, 256, 0); break;
+    }
+    return (e == hipSuccess && n > 0) ? n : 2;
+}
+int front_blocks_per_cu_for(uint32_t sps)
+{
+    switch (sps) {
+    case 3: return front_blocks_per_cu<3>();
+    case 4: return front_blocks_per_cu<4>();
+    case 5: return front_blocks_per_cu<5>();
+    case 6: return front_blocks_per_cu<6>();
+    case 8: return front_blocks_per_cu<8>();
+    case 10: return front_blocks_per_cu<10>();
+    case 12: return front_blocks_per_cu<12>();
+    default: return 2;
+    }
+}
 template <int SPS> void launch_front(const FrontArgs &fa, dim3 grid, hipStream_t s)
 {
-    hipLaunchKernelGGL(recc_front_kernel<SPS>, grid, dim3(256), 0, s, fa);
+    switch (front_depth()) {
+    case 3: hipLaunchKernelGGL((recc_front_kernel<SPS, 3>), grid, dim3(256), 0, s, fa); break;
+    case 2: hipLaunchKernelGGL((recc_front_kernel<SPS, 2>), grid, dim3(256), 0, s, fa); break;
+    default: hipLaunchKernelGGL((recc_front_kernel<SPS, 1>), grid, dim3(256), 0, s, fa); break;
+    }
 }
 
 bool sps_supported(uint32_t sps)
@@ -210,21 +248,25 @@ int run_iq_device(amps_recc *h, const float2 *iq, uint64_t ld, uint32_t nsamp)
     hipStream_t s = h->stream;
     const uint32_t avail = h->r_prev + nsamp;
     const uint32_t P = (avail / 64) * 64, r_new = avail - P;
-    const uint32_t chunk_samples = h->tiles_per_chunk * TILE;
-    const uint32_t nchunks = (P + chunk_samples - 1) / chunk_samples;
-    if (nchunks > h->max_chunks) return -E2BIG;
+    // geometry of the persistent front launch
+    const uint32_t Tc = (P + TILE - 1) / TILE;
+    const uint64_t G = (uint64_t)h->C * Tc;
+    uint32_t nwaves = (uint32_t)std::min<uint64_t>(h->max_waves, (G + MIN_SPAN - 1) / MIN_SPAN);
+    if (nwaves == 0) nwaves = 1;
+    const uint32_t span = (uint32_t)((G + nwaves - 1) / nwaves);
+    if (P && (uint64_t)(Tc + span - 1) / span + 1 > h->max_chunks) return -E2BIG;
     if (P) {
         FrontArgs fa{};
         fa.block = iq; fa.carry = h->carry[h->carry_cur]; fa.ld = ld;
-        fa.r_prev = h->r_prev; fa.avail = avail; fa.P = P; fa.tiles_per_chunk = h->tiles_per_chunk;
+        fa.r_prev = h->r_prev; fa.avail = avail; fa.P = P; fa.tiles_per_channel = Tc; fa.n_channels = h->C; fa.span = span;
         fa.n_done = h->n_done; fa.gring = h->gring; fa.ring_mask = h->ring_words - 1; fa.ring_words = h->ring_words;
         fa.det = h->det; fa.detcount = h->detcount; fa.max_chunks = h->max_chunks; fa.det_cap = h->det_cap;
         fa.status = h->status; fa.dbg_d = h->dbg_d; fa.dbg_S = h->dbg_S; fa.dbg_channel = 0;
         SpanGuard g(h, T_FRONT, P);
         if (debug_sync_enabled())
-            std::fprintf(stderr, "amps_recc[debug]: front grid=(%u,%u) P=%u avail=%u r_prev=%u tpc=%u ld=%llu n_done=%llu ring_words=%u max_chunks=%u det_cap=%u\n",
-                         nchunks, h->C, P, avail, h->r_prev, h->tiles_per_chunk, (unsigned long long)ld, (unsigned long long)h->n_done, h->ring_words, h->max_chunks, h->det_cap);
-        int rc = dispatch_front(h->sps, fa, dim3((nchunks + 3) / 4, h->C), s);
+            std::fprintf(stderr, "amps_recc[debug]: front waves=%u span=%u Tc=%u C=%u P=%u avail=%u r_prev=%u ld=%llu n_done=%llu ring_words=%u max_chunks=%u det_cap=%u\n",
+                         nwaves, span, Tc, h->C, P, avail, h->r_prev, (unsigned long long)ld, (unsigned long long)h->n_done, h->ring_words, h->max_chunks, h->det_cap);
+        int rc = dispatch_front(h->sps, fa, dim3((nwaves + 3) / 4), s);
         if (rc) return rc;
     }
     if (int rc = debug_sync(h, "front")) return rc;
@@ -240,7 +282,7 @@ int run_iq_device(amps_recc *h, const float2 *iq, uint64_t ld, uint32_t nsamp)
         HIP_TRY(hipMemsetAsync(h->capq_count, 0, sizeof(uint32_t), s));
         ResolveArgs ra{};
         ra.det = h->det; ra.detcount = h->detcount; ra.max_chunks = h->max_chunks; ra.det_cap = h->det_cap;
-        ra.nchunks = nchunks; ra.sps = h->sps; ra.n_proc = h->n_done + P;
+        ra.tiles_per_channel = Tc; ra.span = span; ra.sps = h->sps; ra.n_proc = h->n_done + P;
         ra.next_allowed = h->next_allowed; ra.pending = h->pending; ra.capq = h->capq; ra.capq_count = h->capq_count;
         ra.capq_cap = h->cfg.max_bursts; ra.status = h->status;
         {
@@ -328,16 +370,21 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
     rc |= dev_alloc(&h->bursts_dev, (size_t)cfg->max_bursts * AMPS_RECC_CAPTURE_SYMS);
     rc |= dev_alloc(&h->burst_chan_dev, cfg->max_bursts);
     rc |= dev_alloc(&h->nbursts_dev, 1);
+    if (hipHostMalloc((void **)&h->rec_host, sizeof(amps_recc_burst_t) * (size_t)cfg->max_bursts) != hipSuccess) rc |= -ENOMEM;
+    if (hipHostMalloc((void **)&h->hdr_host, 2 * sizeof(uint32_t)) != hipSuccess) rc |= -ENOMEM;
     // IQ seam
     if (!rc && cfg->max_samples_per_push) {
         const uint64_t maxs = cfg->max_samples_per_push;
         h->ring_words = next_pow2(maxs + (uint64_t)h->sps * (AMPS_RECC_CAPTURE_SYMS + 2 * AMPS_RECC_TRIGGER_SYMS + 64) + 2 * TILE) / 64;
-        const uint64_t max_tiles = (maxs + 63 + TILE - 1) / TILE + 1;
-        uint64_t tpc = (max_tiles * C) / 8192;              // aim for >= ~8192 wave-chunks per launch (256 CUs x 16+ waves)
-        tpc = std::max<uint64_t>(32, std::min<uint64_t>(128, tpc));   // halo = 2 tiles per chunk -> 1.6..6 % re-read
-        h->tiles_per_chunk = (uint32_t)tpc;
-        h->max_chunks = (uint32_t)((max_tiles + tpc - 1) / tpc);
-        h->det_cap = (uint32_t)(tpc * TILE / ((uint64_t)AMPS_RECC_TRIGGER_SYMS * h->sps) + 4);
+        // Front launch = one round of resident waves: 4 workgroups (16 waves) per CU, each wave owning an equal
+        // span of the flattened (channel, tile) space.  A channel is covered by at most max_waves/C + 2 segments.
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { amps_recc_destroy(h); return -ENODEV; }
+        h->max_waves = (uint32_t)prop.multiProcessorCount * 4u * (uint32_t)front_blocks_per_cu_for(h->sps);   // exactly one resident round
+        const uint64_t max_tiles = (maxs + 63 + TILE - 1) / TILE;
+        const uint64_t max_span = std::max<uint64_t>(MIN_SPAN, (C * max_tiles + h->max_waves - 1) / h->max_waves);
+        h->max_chunks = (uint32_t)(prop.multiProcessorCount * 32u / C + 3);   // bound for any occupancy
+        h->det_cap = (uint32_t)(max_span * TILE / ((uint64_t)AMPS_RECC_TRIGGER_SYMS * h->sps) + 4);
         rc |= dev_alloc(&h->carry[0], C * CARRY_CAP);
         rc |= dev_alloc(&h->carry[1], C * CARRY_CAP);
         rc |= dev_alloc(&h->gring, C * h->ring_words);
@@ -366,6 +413,8 @@ void amps_recc_destroy(amps_recc_t *h)
                      h->sym_stage, h->bursts_dev, h->burst_chan_dev, h->nbursts_dev, h->dec_out_dev, h->dec_in_dev,
                      h->dec_chan_dev, h->dbg_d, h->dbg_S };
     for (void *p : bufs) if (p) (void)hipFree(p);
+    if (h->rec_host) (void)hipHostFree(h->rec_host);
+    if (h->hdr_host) (void)hipHostFree(h->hdr_host);
     channelizer_destroy(h->chz);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -520,7 +569,7 @@ int amps_recc_drain(amps_recc_t *h, amps_recc_burst_t *out, size_t cap, size_t *
     *nout = 0;
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = h->stream;
-    uint32_t hdr[2] = { 0, 0 };
+    uint32_t *hdr = h->hdr_host;
     HIP_TRY(hipMemcpyAsync(&hdr[0], h->nrecords, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(&hdr[1], h->status, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -531,13 +580,17 @@ int amps_recc_drain(amps_recc_t *h, amps_recc_burst_t *out, size_t cap, size_t *
     if ((hdr[1] & (2u | 4u)) || n > h->cfg.max_bursts) { rc = -ENOSPC; }
     if (n > h->cfg.max_bursts) n = h->cfg.max_bursts;
     if (n) {
-        std::vector<amps_recc_burst_t> tmp(n);
-        HIP_TRY(hipMemcpy(tmp.data(), h->records, sizeof(amps_recc_burst_t) * n, hipMemcpyDeviceToHost));
-        std::sort(tmp.begin(), tmp.end(), [](const amps_recc_burst_t &x, const amps_recc_burst_t &y) {
-            return x.channel != y.channel ? x.channel < y.channel : x.position < y.position;
+        HIP_TRY(hipMemcpyAsync(h->rec_host, h->records, sizeof(amps_recc_burst_t) * n, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        // order by (channel, position) through an index sort: records are 728 bytes, keys are 16
+        std::vector<uint32_t> order(n);
+        for (uint32_t i = 0; i < n; i++) order[i] = i;
+        const amps_recc_burst_t *r = h->rec_host;
+        std::sort(order.begin(), order.end(), [r](uint32_t x, uint32_t y) {
+            return r[x].channel != r[y].channel ? r[x].channel < r[y].channel : r[x].position < r[y].position;
         });
         size_t k = std::min<size_t>(n, cap);
-        if (out && k) std::memcpy(out, tmp.data(), k * sizeof(amps_recc_burst_t));
+        if (out) for (size_t i = 0; i < k; i++) std::memcpy(&out[i], &r[order[i]], sizeof(amps_recc_burst_t));
         *nout = k;
         if (n > cap) rc = -ENOSPC;
     }

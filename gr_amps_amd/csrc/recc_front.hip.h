@@ -72,13 +72,15 @@ struct FrontArgs {
     uint32_t r_prev;         // leftover samples of the previous push held in carry after the halo
     uint32_t avail;          // r_prev + nsamp
     uint32_t P;              // samples processed by this launch (multiple of 64)
-    uint32_t tiles_per_chunk;// wave tiles per wave chunk
+    uint32_t tiles_per_channel; // Tc = ceil(P / 512)
+    uint32_t n_channels;
+    uint32_t span;           // tiles per wave: wave w owns global tiles [w*span, (w+1)*span) of the C*Tc tile space
     uint64_t n_done;         // absolute index of rel sample 0 (multiple of 64)
     uint64_t *gring;         // [C][ring_words] slicer bits, word = abs_sample/64 & ring_mask
     uint32_t ring_mask;      // ring_words - 1
     uint32_t ring_words;
-    uint64_t *det;           // [C][max_chunks][det_cap]  (abs_sample << 8 | run_len-1), ordered
-    uint32_t *detcount;      // [C][max_chunks]
+    uint64_t *det;           // [C][max_chunks][det_cap]  (abs_sample << 8 | run_len-1), ordered;
+    uint32_t *detcount;      // [C][max_chunks]           "chunk" = k-th wave segment of the channel
     uint32_t max_chunks;
     uint32_t det_cap;
     uint32_t *status;        // bit 0: detection list overflow
@@ -89,58 +91,132 @@ struct FrontArgs {
 
 typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));  // two fc32 samples, 8-byte aligned
 
-__device__ __forceinline__ float fm_phase(float xr, float xi, float pr, float pi_)
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// The discriminator of include/amps_recc_numerics.h for the two samples a lane holds (A = s.xy with
+// predecessor p, B = s.zw with predecessor A), written on 2-vectors so that hipcc emits v_pk_mul /
+// v_pk_fma / v_pk_add: measured on MI355X a packed fp32 op issues in ~4.8 cycles per wave against
+// ~4.3 for a scalar one (scripts/ubench_pk.hip), i.e. 1.8x the arithmetic per issue slot, and this
+// kernel is VALU-issue bound.  ~19 instructions per sample instead of ~30.
+__device__ __forceinline__ f2 fm_phase_pair(float4 s, float pr, float pi_)
 {
-    float re = __builtin_fmaf(xr, pr, xi * pi_);
-    float im = __builtin_fmaf(xi, pr, -(xr * pi_));
-    float ax = __builtin_fabsf(re), ay = __builtin_fabsf(im);
-    float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
-    float q = mx > 0.0f ? mn / mx : 0.0f;
-    float z = q * q;
-    float p = AMPS_ATAN_C5;
-    p = __builtin_fmaf(p, z, AMPS_ATAN_C4);
-    p = __builtin_fmaf(p, z, AMPS_ATAN_C3);
-    p = __builtin_fmaf(p, z, AMPS_ATAN_C2);
-    p = __builtin_fmaf(p, z, AMPS_ATAN_C1);
-    p = __builtin_fmaf(p, z, AMPS_ATAN_C0);
-    float a = p * q;
-    if (ay > ax) a = AMPS_PI_2_F - a;
-    if (re < 0.0f) a = AMPS_PI_F - a;
-    if (im < 0.0f) a = -a;
-    return a;
+    const f2 xa = { s.x, s.y }, xb = { s.z, s.w };
+    // t = x * conj(p): (re, im) = (xr*pr + xi*pi, xi*pr - xr*pi), packed over (re, im)
+    const f2 ma = (f2){ s.y, s.x } * (f2){ pi_, -pi_ };
+    const f2 ta = __builtin_elementwise_fma(xa, (f2){ pr, pr }, ma);
+    const f2 mb = (f2){ s.w, s.z } * (f2){ s.y, -s.y };
+    const f2 tb = __builtin_elementwise_fma(xb, (f2){ s.x, s.x }, mb);
+    // from here on packed over the two samples
+    const f2 re = { ta.x, tb.x }, im = { ta.y, tb.y };
+    const float axa = __builtin_fabsf(ta.x), aya = __builtin_fabsf(ta.y);
+    const float axb = __builtin_fabsf(tb.x), ayb = __builtin_fabsf(tb.y);
+    const f2 mx = { __builtin_fmaxf(__builtin_fmaxf(axa, aya), AMPS_MX_FLOOR), __builtin_fmaxf(__builtin_fmaxf(axb, ayb), AMPS_MX_FLOOR) };
+    const f2 mn = { __builtin_fminf(axa, aya), __builtin_fminf(axb, ayb) };
+    f2 r = { __uint_as_float(AMPS_RCP_MAGIC - __float_as_uint(mx.x)), __uint_as_float(AMPS_RCP_MAGIC - __float_as_uint(mx.y)) };
+    const f2 one = { 1.0f, 1.0f };
+    f2 e;
+    e = __builtin_elementwise_fma(-mx, r, one); r = __builtin_elementwise_fma(r, e, r);
+    e = __builtin_elementwise_fma(-mx, r, one); r = __builtin_elementwise_fma(r, e, r);
+    e = __builtin_elementwise_fma(-mx, r, one); r = __builtin_elementwise_fma(r, e, r);
+    const f2 q = mn * r;
+    const f2 z = q * q;
+    f2 p = { AMPS_ATAN_C5, AMPS_ATAN_C5 };
+    p = __builtin_elementwise_fma(p, z, (f2){ AMPS_ATAN_C4, AMPS_ATAN_C4 });
+    p = __builtin_elementwise_fma(p, z, (f2){ AMPS_ATAN_C3, AMPS_ATAN_C3 });
+    p = __builtin_elementwise_fma(p, z, (f2){ AMPS_ATAN_C2, AMPS_ATAN_C2 });
+    p = __builtin_elementwise_fma(p, z, (f2){ AMPS_ATAN_C1, AMPS_ATAN_C1 });
+    p = __builtin_elementwise_fma(p, z, (f2){ AMPS_ATAN_C0, AMPS_ATAN_C0 });
+    f2 a = p * q;
+    const f2 a_swapped = (f2){ AMPS_PI_2_F, AMPS_PI_2_F } - a;
+    a.x = aya > axa ? a_swapped.x : a.x;
+    a.y = ayb > axb ? a_swapped.y : a.y;
+    const f2 a_reflect = (f2){ AMPS_PI_F, AMPS_PI_F } - a;
+    a.x = re.x < 0.0f ? a_reflect.x : a.x;
+    a.y = re.y < 0.0f ? a_reflect.y : a.y;
+    return (f2){ __builtin_copysignf(a.x, im.x), __builtin_copysignf(a.y, im.y) };
 }
 
-constexpr int DRING = 2 * TILE;                                   // demod ring: 2 tiles
-__device__ __forceinline__ int didx(int n) { return n + (n >> 3); } // padded LDS index, n in [0, DRING)
+// Per-wave LDS demod buffers (two, used alternately): 16 floats of history (the tail of the previous
+// tile, written by the previous tile's P1 into THIS buffer) then the 512 floats of the tile; every 8
+// floats padded by one, so the boxcar reads of lane L hit bank 9*L + const (conflict free) and every
+// LDS address is a lane-constant base plus an immediate offset.
+constexpr int DHIST = 16;
+__host__ __device__ constexpr int didx(int n) { return n + (n >> 3); }   // n = DHIST + tile-local sample
+constexpr int DBUF = ((didx(DHIST + TILE - 1) + 1 + 7) / 8) * 8;        // 600 floats per buffer
+constexpr int GW32 = 4 * TILE / 32;                                     // 64 dwords: 4-tile bit ring (+1 mirror)
 
-template <int SPS>
-__global__ __launch_bounds__(256) void recc_front_kernel(FrontArgs a)
+// trigger symbol i as an xor mask for the xnor test (symbol 1 -> 0, symbol 0 -> ~0)
+__device__ __forceinline__ uint32_t trig_xor(int i)
+{
+    uint32_t w = i < 32 ? (uint32_t)TRIG_LO : i < 64 ? (uint32_t)(TRIG_LO >> 32) : (uint32_t)TRIG_HI;
+    return ((w >> (i & 31)) & 1u) - 1u;
+}
+
+// lane i <- lane i-1 of the same wave, lane 0 <- `lane0` (one DPP mov, no LDS traffic)
+__device__ __forceinline__ float shift_in(float v, float lane0)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lane0), __float_as_int(v), 0x138 /* wave_shr:1 */,
+                                                      0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane63(float v)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+template <int SPS, int DEPTH>
+__global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc_front_kernel(FrontArgs a)
 {
     static_assert(SPS >= 2 && SPS <= 16, "samples per symbol");
     constexpr int H = SPS - 1;                  // boxcar history
     constexpr int D = AMPS_DEDUP_SYMBOLS * SPS; // dedup / run window in samples (<= 32)
-    constexpr int GW = 4 * TILE / 64;           // words in the per-wave bit rings (4 tiles)
-    __shared__ float    s_d_all[4][DRING + DRING / 8];
-    __shared__ uint64_t s_g_all[4][GW];
-    __shared__ uint64_t s_m_all[4][GW];
+    static_assert(H <= DHIST, "history prefix too small");
+    __shared__ float    s_d_all[4][2 * DBUF];
+    __shared__ uint32_t s_g_all[4][GW32 + 2];   // [GW32] mirrors [0] so a tap can always read dwords qd, qd+1
+    __shared__ uint32_t s_m_all[4][GW32];
 
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const int c = blockIdx.y;
-    const int chunk = blockIdx.x * 4 + wv;
-    const int64_t chunk_start = (int64_t)chunk * a.tiles_per_chunk * TILE;   // rel
-    if (chunk_start >= (int64_t)a.P) return;     // whole wave leaves; no barriers are used below
-    int64_t chunk_len = (int64_t)a.P - chunk_start;
-    if (chunk_len > (int64_t)a.tiles_per_chunk * TILE) chunk_len = (int64_t)a.tiles_per_chunk * TILE;
-    const int K = (int)((chunk_len + TILE - 1) / TILE);  // real tiles in this chunk
+    // Persistent, evenly split: the launch has exactly as many waves as the chip holds at once and
+    // wave w owns the contiguous span [w*span, (w+1)*span) of the flattened (channel, tile) space, so
+    // every wave does the same amount of work in ONE round (no tail round of a quantised grid).  A
+    // span that crosses a channel boundary is processed as two (or more) segments.
+    const uint32_t w_id = blockIdx.x * 4 + wv;
+    const uint64_t Tc = a.tiles_per_channel;
+    const uint64_t g_end_all = (uint64_t)a.n_channels * Tc;
+    uint64_t g0 = (uint64_t)w_id * a.span;
+    uint64_t g1 = g0 + a.span; if (g1 > g_end_all) g1 = g_end_all;
     const int64_t words_end = (int64_t)a.P / 64;          // rel word index limit of this launch
-
+    const int r_prev = (int)a.r_prev, avail = (int)a.avail;
     float *s_d = s_d_all[wv];
-    uint64_t *s_g = s_g_all[wv];
-    uint64_t *s_m = s_m_all[wv];
+    uint32_t *s_g = s_g_all[wv];
+    uint32_t *s_m = s_m_all[wv];
+    // lane-constant pieces of the LDS addressing (everything else is an immediate offset)
+    const int dw_off = 2 * lane + (lane >> 2);          // P1 writes: didx(DHIST + 128q + 2*lane + e)
+    const int dr_off = 9 * lane;                        // P2 reads:  didx(DHIST - H + 8*lane + m)
+    const int wq = lane >> 2;                           // P3: dword of the tile this quad owns (0..15)
+    const int part = lane & 3;                          // P3: 4 lanes share a dword
+    // prefilter taps: the symbols part+4u (u = 0..3) before the last one; relative to the slot base the
+    // bit offset is lane-constant, so the shift and the xor mask never change and only the dword moves
+    uint32_t pre_xor[4];
+    int pre_q0[4], pre_sh[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int off = 32 * wq - SPS * (part + 4 * u);          // may be negative: previous tiles
+        pre_xor[u] = trig_xor(TRIG - 1 - part - 4 * u);
+        pre_q0[u] = off >> 5;                                     // arithmetic shift
+        pre_sh[u] = off & 31;
+    }
+
+  while (g0 < g1) {                                    // one segment = a run of tiles inside one channel
+    const int c = (int)(g0 / Tc);
+    const uint32_t t_lo = (uint32_t)(g0 - (uint64_t)c * Tc);
+    uint32_t t_hi = t_lo + (uint32_t)(g1 - g0); if (t_hi > Tc) t_hi = (uint32_t)Tc;
+    const uint32_t chunk = w_id - (uint32_t)(((uint64_t)c * Tc) / a.span);   // k-th segment of this channel
+    const int64_t chunk_start = (int64_t)t_lo * TILE;    // rel
+    const int K = (int)(t_hi - t_lo);                    // real tiles in this segment
+    g0 += (uint64_t)K;
     const float2 *blk = a.block + (uint64_t)c * a.ld;
     const float2 *car = a.carry + (uint64_t)c * CARRY_CAP;
-    const int r_prev = (int)a.r_prev, avail = (int)a.avail;
 
     auto fetch = [&](int64_t i) -> float2 {   // generic path: carry then block; zero outside the data
         if (i >= avail || i < -(int64_t)HALO) return make_float2(0.f, 0.f);
@@ -162,42 +238,53 @@ __global__ __launch_bounds__(256) void recc_front_kernel(FrontArgs a)
         }
     };
 
-    if (lane < GW) { s_g[lane] = ~0ull; s_m[lane] = 0; }
-    for (int i = lane; i < DRING + DRING / 8; i += 64) s_d[i] = 0.f;
+    s_g[lane] = ~0u;
+    if (lane < 2) s_g[GW32 + lane] = ~0u;
+    s_m[lane] = 0u;
+    for (int i = lane; i < 2 * DBUF; i += 64) s_d[i] = 0.f;
 
-    float4 cur[4], nxt[4];
+    float4 cur[4], nxt[DEPTH][4];                // tile k in use, tiles k+1..k+DEPTH in flight (DEPTH x 4 KiB per wave)
     float last_x = 0.f, last_y = 0.f;            // last sample of the previous tile (wave-uniform)
     uint32_t ndet = 0;                           // hits appended by this wave (wave-uniform)
+    bool hit_prev = false;                       // the previous tile had a trigger hit (wave-uniform)
     load_tile(cur, chunk_start - HALO);
+#pragma unroll
+    for (int d = 0; d + 1 < DEPTH; d++) load_tile(nxt[d], chunk_start - HALO + (d + 1) * TILE);   // K >= 1: all exist up to d = 1
 
     // k = -2, -1 are the halo tiles [chunk_start-1024, chunk_start): recomputed, never stored or emitted
     for (int k = -2; k < K; k++) {
         const int64_t t0 = chunk_start + (int64_t)k * TILE;   // rel start of this tile
         const int slot = (k + 2) & 3;                          // bit-ring slot of this tile
-        const int dbase = ((k + 2) & 1) * TILE;                // demod-ring base of this tile
+        float *const dcur = s_d + ((k + 2) & 1) * DBUF;        // demod buffer of this tile
+        float *const dnxt = s_d + ((k + 3) & 1) * DBUF;        // ... of the next tile (gets our tail as history)
         // ---- P1: prefetch the next tile, demodulate this one into LDS ----
-        if (k + 1 < K) load_tile(nxt, t0 + TILE);
+        if (k + DEPTH < K) load_tile(nxt[DEPTH - 1], t0 + DEPTH * TILE);
+        float *const dw = dcur + dw_off;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            float pr = __shfl_up(cur[q].z, 1), pi_ = __shfl_up(cur[q].w, 1);
-            float er, ei;
-            if (q == 0) { er = last_x; ei = last_y; }
-            else { er = __shfl(cur[q - 1].z, 63); ei = __shfl(cur[q - 1].w, 63); }
-            if (lane == 0) { pr = er; pi_ = ei; }
-            const int n = dbase + 128 * q + 2 * lane;
-            s_d[didx(n)] = fm_phase(cur[q].x, cur[q].y, pr, pi_);
-            s_d[didx(n + 1)] = fm_phase(cur[q].z, cur[q].w, cur[q].x, cur[q].y);
+            const float ex = q == 0 ? last_x : lane63(cur[q - 1].z);
+            const float ey = q == 0 ? last_y : lane63(cur[q - 1].w);
+            const float pr = shift_in(cur[q].z, ex), pi_ = shift_in(cur[q].w, ey);
+            const f2 dd = fm_phase_pair(cur[q], pr, pi_);
+            const float d0 = dd.x, d1 = dd.y;
+            dw[didx(DHIST + 128 * q)] = d0;
+            dw[didx(DHIST + 128 * q) + 1] = d1;
+            if (q == 3 && lane >= 56) {          // samples 496..511: also the history prefix of the next tile
+                dnxt[didx(2 * (lane - 56))] = d0;
+                dnxt[didx(2 * (lane - 56)) + 1] = d1;
+            }
         }
-        last_x = __shfl(cur[3].z, 63);
-        last_y = __shfl(cur[3].w, 63);
+        last_x = lane63(cur[3].z);
+        last_y = lane63(cur[3].w);
         __builtin_amdgcn_wave_barrier();
         // ---- P2: boxcar over one symbol (aligned pair sums), slice, pack 8 bits per lane ----
         {
+            const float *const dr = dcur + dr_off;
             float v[H + 8];
 #pragma unroll
-            for (int m = 0; m < H + 8; m++) v[m] = s_d[didx((dbase + 8 * lane - H + m) & (DRING - 1))];
+            for (int m = 0; m < H + 8; m++) v[m] = dr[didx(DHIST - H + m)];
             unsigned byte = 0;
-            const bool tap = a.dbg_d && (uint32_t)c == a.dbg_channel && k >= 0;
+            const bool dbg = a.dbg_d && (uint32_t)c == a.dbg_channel && k >= 0;   // diagnostic taps (tests only)
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 // window v[q .. q+H]; v[j] has absolute parity (j + H) & 1 because 8*lane is even
@@ -210,60 +297,66 @@ __global__ __launch_bounds__(256) void recc_front_kernel(FrontArgs a)
                 for (int u = lead ? 0 : 1; u < npairs; u++) s = s + (v[j0 + 2 * u] + v[j0 + 2 * u + 1]);
                 if (trail) s = s + v[q + H];
                 byte |= (s >= 0.0f ? 1u : 0u) << q;
-                if (tap) {
+                if (dbg) {
                     int64_t rel = t0 + 8 * lane + q;
                     if (rel < (int64_t)a.P) { a.dbg_d[rel] = v[q + H]; a.dbg_S[rel] = s; }
                 }
             }
             ((uint8_t *)s_g)[slot * (TILE / 8) + lane] = (uint8_t)byte;
+            if (slot == 0 && lane < 8) ((uint8_t *)s_g)[GW32 * 4 + lane] = (uint8_t)byte;   // mirror of dwords 0,1
         }
         __builtin_amdgcn_wave_barrier();
         // ---- P3a: bit-parallel exact match of the 74-symbol trigger; publish slicer words ----
-        const int wl = lane & 7;             // word within the tile (0..7)
-        const int part = lane >> 3;          // 8 lanes share a word
+        bool hit = false;
         {
-            const int bitbase = slot * TILE + 64 * wl;
-            auto tap_word = [&](int i) -> uint64_t {   // 64 phases of tap i, 1 = symbol matches
-                int B = (bitbase - SPS * (TRIG - 1 - i)) & (4 * TILE - 1);
-                int qw = B >> 6, sh = B & 63;
-                uint64_t lo = s_g[qw], hi = s_g[(qw + 1) & (GW - 1)];
-                uint64_t val = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
-                uint64_t t = (i < 64 ? (TRIG_LO >> i) : (TRIG_HI >> (i - 64))) & 1ull;
-                return t ? val : ~val;
-            };
-            auto and_parts = [&](uint64_t x) -> uint64_t {
-                x &= __shfl_xor(x, 8);
-                x &= __shfl_xor(x, 16);
-                x &= __shfl_xor(x, 32);
+            auto and_quad = [&](uint32_t x) -> uint32_t {
+                x &= (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+                x &= (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
                 return x;
             };
-            // prefilter: the last 16 symbols (all inside the word-sync part), 2 taps per lane
-            uint64_t acc = and_parts(tap_word(TRIG - 1 - part) & tap_word(TRIG - 9 - part));
-            if (__ballot(acc != 0)) {        // rare: evaluate all 74 taps
-                acc = ~0ull;
-                for (int i = part; i < TRIG; i += 8) acc &= tap_word(i);
-                acc = and_parts(acc);
+            // prefilter: the last 16 symbols (all inside the word-sync part), 4 taps per lane
+            uint32_t acc = ~0u;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int qd = (pre_q0[u] + slot * (TILE / 32)) & (GW32 - 1);
+                const uint32_t lo = s_g[qd], hi = s_g[qd + 1];          // [GW32] mirrors [0]
+                acc &= __builtin_amdgcn_alignbit(hi, lo, pre_sh[u]) ^ pre_xor[u];
+            }
+            acc = and_quad(acc);
+            if (__ballot(acc != 0)) {        // rare (2^-16 per phase on noise): evaluate all 74 taps
+                const int bitbase = slot * TILE + 32 * wq;
+                acc = ~0u;
+                for (int i = part; i < TRIG; i += 4) {
+                    const int B = (bitbase - SPS * (TRIG - 1 - i)) & (4 * TILE - 1);
+                    const int qd = B >> 5;
+                    acc &= __builtin_amdgcn_alignbit(s_g[qd + 1], s_g[qd], B & 31) ^ trig_xor(i);
+                }
+                acc = and_quad(acc);
+                hit = __ballot(acc != 0) != 0;
             }
             if (part == 0) {
-                s_m[slot * (TILE / 64) + wl] = acc;
-                const int64_t relw = t0 / 64 + wl;      // rel word index (t0 is a multiple of 64)
+                s_m[slot * (TILE / 32) + wq] = acc;
+                const int64_t relw = t0 / 64 + (wq >> 1);      // rel 64-bit word index
                 if (k >= 0 && relw < words_end) {
                     uint64_t absw = a.n_done / 64 + (uint64_t)relw;
-                    a.gring[(uint64_t)c * a.ring_words + (absw & a.ring_mask)] = s_g[slot * (TILE / 64) + wl];
+                    uint32_t *g32 = (uint32_t *)(a.gring + (uint64_t)c * a.ring_words + (absw & a.ring_mask));
+                    g32[wq & 1] = s_g[slot * (TILE / 32) + wq];
                 }
             }
         }
         __builtin_amdgcn_wave_barrier();
         // ---- P3b: emit run starts located in [previous tile word 7, this tile words 0..6] ----
-        if (k >= 0) {
+        if (k >= 0 && (hit || hit_prev)) {               // wave-uniform and rare
+            const uint64_t *s_m64 = (const uint64_t *)s_m;
+            constexpr int GW = GW32 / 2;
             uint64_t starts = 0, mcur = 0, mnext = 0;
             int64_t relw = 0;
             if (lane < 8) {
                 const int ring_w = (slot * (TILE / 64) + lane - 1) & (GW - 1);   // word examined
                 relw = t0 / 64 + lane - 1;
-                const uint64_t mprev = s_m[(ring_w - 1) & (GW - 1)];
-                mcur = s_m[ring_w];
-                mnext = s_m[(ring_w + 1) & (GW - 1)];
+                const uint64_t mprev = s_m64[(ring_w - 1) & (GW - 1)];
+                mcur = s_m64[ring_w];
+                mnext = s_m64[(ring_w + 1) & (GW - 1)];
                 uint64_t smear = 0;
 #pragma unroll
                 for (int s = 1; s <= D; s++) smear |= (mcur << s) | (mprev >> (64 - s));
@@ -273,7 +366,7 @@ __global__ __launch_bounds__(256) void recc_front_kernel(FrontArgs a)
                 if (absw < 0 || relw + 1 >= words_end) starts = 0;
             }
             uint64_t who = __ballot(starts != 0);
-            while (who) {                                 // rare: ordered append, lane by lane
+            while (who) {                                 // ordered append, lane by lane
                 const int l = __ffsll((unsigned long long)who) - 1;
                 who &= who - 1;
                 const int cnt = __popcll(__shfl(starts, l));
@@ -295,10 +388,16 @@ __global__ __launch_bounds__(256) void recc_front_kernel(FrontArgs a)
                 ndet += (uint32_t)cnt;
             }
         }
+        hit_prev = hit;
 #pragma unroll
-        for (int q = 0; q < 4; q++) cur[q] = nxt[q];
+        for (int q = 0; q < 4; q++) {
+            cur[q] = nxt[0][q];
+#pragma unroll
+            for (int d = 0; d + 1 < DEPTH; d++) nxt[d][q] = nxt[d + 1][q];
+        }
     }
     if (lane == 0) a.detcount[(uint64_t)c * a.max_chunks + chunk] = ndet < a.det_cap ? ndet : a.det_cap;
+  }   // next segment of this wave's span
 }
 
 // carry[c][k] = V(P - HALO + k) for k in [0, HALO + r_new): the halo the next push recomputes from

@@ -20,7 +20,8 @@ namespace amps {
 struct ResolveArgs {
     const uint64_t *det;       // [C][max_chunks][det_cap]
     const uint32_t *detcount;  // [C][max_chunks]
-    uint32_t max_chunks, det_cap, nchunks;
+    uint32_t max_chunks, det_cap;
+    uint32_t tiles_per_channel, span;   // segment geometry of the front launch (recc_front.hip.h)
     uint32_t sps;
     uint64_t n_proc;           // absolute samples processed after this push
     uint64_t *next_allowed;    // [C]
@@ -50,11 +51,14 @@ __global__ __launch_bounds__(64) void recc_resolve_kernel(ResolveArgs a)
 
     if (pend != ~0ull && pend + span_done < a.n_proc) { enqueue(pend); pend = ~0ull; }
 
+    // segments of channel c: waves floor(c*Tc/span) .. floor((c*Tc + Tc - 1)/span), in stream order
+    const uint64_t gs = (uint64_t)c * a.tiles_per_channel;
+    const uint32_t nchunks = (uint32_t)((gs + a.tiles_per_channel - 1) / a.span - gs / a.span) + 1;
     const uint32_t *cnt = a.detcount + (uint64_t)c * a.max_chunks;
     const uint64_t *det = a.det + (uint64_t)c * a.max_chunks * a.det_cap;
-    for (uint32_t cb = 0; cb < a.nchunks; cb += 64) {
+    for (uint32_t cb = 0; cb < nchunks; cb += 64) {
         uint32_t ch = cb + lane;
-        uint32_t n = ch < a.nchunks ? cnt[ch] : 0u;
+        uint32_t n = ch < nchunks ? cnt[ch] : 0u;
         uint64_t any = __ballot(n != 0);
         while (any) {                                 // chunks in order, hits in order (both rare)
             int l = __ffsll((unsigned long long)any) - 1;

@@ -9,14 +9,18 @@
  *
  *   re = fmaf(xr, pr, xi*pi)          t = x[n] * conj(x[n-1])
  *   im = fmaf(xi, pr, -(xr*pi))
- *   ax = |re|  ay = |im|   mx = max(ax,ay)   mn = min(ax,ay)
- *   q  = mx > 0 ? mn / mx : 0         (IEEE correctly rounded division)
+ *   ax = |re|  ay = |im|   mx = max(ax, ay, 2^-100)   mn = min(ax, ay)
+ *   r  = as_float(0x7EF311C7 - as_uint(mx))            reciprocal seed (12 % error), then three
+ *   e  = fmaf(-mx, r, 1); r = fmaf(r, e, r)   (x3)     Newton steps -> |r*mx - 1| < 1e-7
+ *   q  = mn * r                                         (no hardware rcp/div: their rounding is not
+ *                                                        reproducible on a CPU, this sequence is;
+ *                                                        x = 0 gives mn = 0 -> q = 0 -> d = 0)
  *   z  = q*q
  *   p  = C5; p = fmaf(p,z,C4); ... ; p = fmaf(p,z,C0)        (Horner)
  *   a  = p*q
  *   if (ay > ax) a = PI_2 - a
  *   if (re < 0)  a = PI   - a
- *   if (im < 0)  a = -a
+ *   a  = copysign(a, im)                               (atan2 sign convention, -0 included)
  *   d[n] = a                                          |d[n] - atan2(im,re)| <= 4e-6 rad
  *
  *   boxcar over one Manchester symbol (sps samples ending at n), summed oldest to newest over
@@ -38,6 +42,8 @@
 #define AMPS_ATAN_C3 -0x1.dce1c0p-4f
 #define AMPS_ATAN_C4  0x1.af48f4p-5f
 #define AMPS_ATAN_C5 -0x1.800270p-7f
+#define AMPS_RCP_MAGIC 0x7EF311C7u
+#define AMPS_MX_FLOOR  0x1p-100f
 #define AMPS_PI_F     0x1.921fb6p+1f
 #define AMPS_PI_2_F   0x1.921fb6p+0f
 

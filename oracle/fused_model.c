@@ -18,8 +18,15 @@ static inline float fm_phase(float xr, float xi, float pr, float pi_)
     float re = fmaf(xr, pr, xi * pi_);
     float im = fmaf(xi, pr, -(xr * pi_));
     float ax = fabsf(re), ay = fabsf(im);
-    float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
-    float q = mx > 0.0f ? mn / mx : 0.0f;
+    float mx = fmaxf(fmaxf(ax, ay), AMPS_MX_FLOOR), mn = fminf(ax, ay);
+    union { float f; uint32_t u; } cv;
+    cv.f = mx;
+    cv.u = AMPS_RCP_MAGIC - cv.u;
+    float r = cv.f, e;
+    e = fmaf(-mx, r, 1.0f); r = fmaf(r, e, r);
+    e = fmaf(-mx, r, 1.0f); r = fmaf(r, e, r);
+    e = fmaf(-mx, r, 1.0f); r = fmaf(r, e, r);
+    float q = mn * r;
     float z = q * q;
     float p = AMPS_ATAN_C5;
     p = fmaf(p, z, AMPS_ATAN_C4);
@@ -30,8 +37,7 @@ static inline float fm_phase(float xr, float xi, float pr, float pi_)
     float a = p * q;
     if (ay > ax) a = AMPS_PI_2_F - a;
     if (re < 0.0f) a = AMPS_PI_F - a;
-    if (im < 0.0f) a = -a;
-    return a;
+    return copysignf(a, im);
 }
 
 void orc_fm_discriminator(const float *iq, size_t n, float *d)

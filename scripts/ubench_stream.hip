@@ -1,0 +1,90 @@
+// ubench_stream.hip -- what HBM read bandwidth does the wave-stream access pattern allow on MI355X?
+// Build+run on the GPU box:  hipcc --offload-arch=gfx950 -O3 scripts/ubench_stream.hip -o /tmp/ub && /tmp/ub
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+// A: plain grid-stride float4 read (sum) -- the linear-stream ceiling
+__global__ __launch_bounds__(256) void k_linear(const float4 *p, size_t n4, float *out)
+{
+    float acc = 0.f;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) { float4 v = p[i]; acc += v.x + v.y + v.z + v.w; }
+    if (acc == 12345.f) out[0] = acc;
+}
+// B: one wave per (channel, chunk), 512-sample (4 KiB) tiles, DEPTH tiles in flight, WORK dummy fma per element
+template <int DEPTH, int WORK>
+__global__ __launch_bounds__(256) void k_wave(const float4 *p, size_t ld4, int tiles_per_chunk, int tiles_total, float *out)
+{
+    extern __shared__ float occupancy_limiter[];      // dynamic LDS only caps workgroups per CU
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = blockIdx.y, chunk = blockIdx.x * 4 + wv;
+    if (ld4 == 1) occupancy_limiter[threadIdx.x] = 0.f;
+    const int t0 = chunk * tiles_per_chunk;
+    if (t0 >= tiles_total) return;
+    int t1 = t0 + tiles_per_chunk; if (t1 > tiles_total) t1 = tiles_total;
+    const float4 *base = p + (size_t)c * ld4 + lane;
+    float4 buf[DEPTH][4];
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) buf[d][q] = base[(size_t)(t0 + d < t1 ? t0 + d : t0) * 256 + 64 * q];
+    float acc = 0.f;
+    for (int t = t0; t < t1; t++) {
+        float4 cur[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) cur[q] = buf[0][q];
+#pragma unroll
+        for (int d = 0; d + 1 < DEPTH; d++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) buf[d][q] = buf[d + 1][q];
+        if (t + DEPTH < t1) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) buf[DEPTH - 1][q] = base[(size_t)(t + DEPTH) * 256 + 64 * q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            float x = cur[q].x, y = cur[q].y, z = cur[q].z, w = cur[q].w;
+#pragma unroll
+            for (int r = 0; r < WORK; r++) { x = __builtin_fmaf(x, y, z); y = __builtin_fmaf(y, z, w); z = __builtin_fmaf(z, w, x); w = __builtin_fmaf(w, x, y); }
+            acc += x + y + z + w;
+        }
+    }
+    if (acc == 12345.f) out[0] = acc;
+}
+
+template <typename F> float time_ms(F f, int reps = 10)
+{
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    f(); hipDeviceSynchronize();
+    hipEventRecord(a); for (int i = 0; i < reps; i++) f(); hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b); return ms / reps;
+}
+
+int main()
+{
+    const int C = 832; const size_t N = 1 << 18; const size_t ld4 = N / 2;     // float4 = 2 samples
+    const size_t bytes = (size_t)C * N * 8;
+    float4 *d; float *out; CK(hipMalloc(&d, bytes)); CK(hipMalloc(&out, 4)); CK(hipMemset(d, 0x11, bytes));
+    const int tiles_total = N / 512;
+    printf("bytes per pass %.3f GB\n", bytes / 1e9);
+    float ms = time_ms([&] { hipLaunchKernelGGL(k_linear, dim3(256 * 8), dim3(256), 0, 0, d, bytes / 16, out); });
+    printf("A linear float4 read            : %.3f ms  %.0f GB/s\n", ms, bytes / ms / 1e6);
+    for (int wgs_per_cu : { 8, 6, 5, 4, 3, 2 }) {      // 4 waves per workgroup
+        const int tpc = 52;
+        int nch = (tiles_total + tpc - 1) / tpc;
+        dim3 g((nch + 3) / 4, C);
+        size_t lds = 160 * 1024 / wgs_per_cu - 512;
+        hipFuncSetAttribute((const void *)k_wave<1, 20>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void *)k_wave<2, 20>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void *)k_wave<3, 20>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        ms = time_ms([&] { hipLaunchKernelGGL((k_wave<1, 20>), g, dim3(256), lds, 0, d, ld4, tpc, tiles_total, out); });
+        printf("waves/CU %2d depth1 w20 : %.3f ms  %.0f GB/s\n", wgs_per_cu * 4, ms, bytes / ms / 1e6);
+        ms = time_ms([&] { hipLaunchKernelGGL((k_wave<2, 20>), g, dim3(256), lds, 0, d, ld4, tpc, tiles_total, out); });
+        printf("waves/CU %2d depth2 w20 : %.3f ms  %.0f GB/s\n", wgs_per_cu * 4, ms, bytes / ms / 1e6);
+        ms = time_ms([&] { hipLaunchKernelGGL((k_wave<3, 20>), g, dim3(256), lds, 0, d, ld4, tpc, tiles_total, out); });
+        printf("waves/CU %2d depth3 w20 : %.3f ms  %.0f GB/s\n", wgs_per_cu * 4, ms, bytes / ms / 1e6);
+    }
+    return 0;
+}
