@@ -119,7 +119,7 @@ def main():
 
     def step():
         r.push_iq(batch)
-        return r.drain()
+        return r.drain(copy=False)
 
     for _ in range(a.warmup):
         recs = step()

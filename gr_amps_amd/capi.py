@@ -160,8 +160,8 @@ class Recc:
             raise AmpsError(rc, "amps_recc_create")
 
     def close(self):
-        if getattr(self, "_h", None):
-            load().amps_recc_destroy(self._h)
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.amps_recc_destroy(self._h)
             self._h = None
 
     __del__ = close
@@ -235,16 +235,18 @@ class Recc:
         if rc:
             raise AmpsError(rc, "amps_recc_push_wideband")
 
-    def drain(self, cap=None):
+    def drain(self, cap=None, copy=True):
+        """Synchronise and return the decoded bursts since the last drain, sorted by (channel, position).
+        copy=False returns a view of a buffer owned by this handle, valid until the next drain()."""
         cap = cap or self.max_bursts
         out = getattr(self, "_drain_buf", None)
         if out is None or out.shape[0] < cap:
-            out = self._drain_buf = np.empty(cap, BURST_DTYPE)   # reused: a drain should not cost a 3 MB memset
+            out = self._drain_buf = np.empty(cap, BURST_DTYPE)
         nout = C.c_size_t(0)
         rc = load().amps_recc_drain(self._h, _hostptr(out), cap, C.byref(nout))
         if rc:
             raise AmpsError(rc, "amps_recc_drain")
-        return out[:nout.value].copy()
+        return out[:nout.value].copy() if copy else out[:nout.value]
 
     def debug_demod(self, iq):
         iq = np.ascontiguousarray(iq, np.complex64).reshape(-1)

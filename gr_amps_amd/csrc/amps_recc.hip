@@ -63,7 +63,7 @@ struct amps_recc {
     amps_recc_burst_t *records = nullptr;
     uint32_t *nrecords = nullptr;
     uint32_t *status = nullptr;
-    amps_recc_burst_t *rec_host = nullptr;   // pinned staging for drain()
+    amps_recc_burst_t *rec_host = nullptr;   // mapped pinned host memory: the capture kernel writes records here directly
     uint32_t *hdr_host = nullptr;             // pinned {nrecords, status}
     float2 *stage_iq = nullptr;       // device staging for host-resident IQ
     size_t stage_iq_samples = 0;
@@ -360,7 +360,6 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
     int rc = 0;
     const size_t C = h->C;
     // results + symbol seam (always present)
-    rc |= dev_alloc(&h->records, cfg->max_bursts);
     rc |= dev_alloc(&h->nrecords, 1);
     rc |= dev_alloc(&h->status, 1);
     rc |= dev_alloc(&h->symbuf, C * AMPS_RECC_SYMBUF);
@@ -370,7 +369,10 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
     rc |= dev_alloc(&h->bursts_dev, (size_t)cfg->max_bursts * AMPS_RECC_CAPTURE_SYMS);
     rc |= dev_alloc(&h->burst_chan_dev, cfg->max_bursts);
     rc |= dev_alloc(&h->nbursts_dev, 1);
-    if (hipHostMalloc((void **)&h->rec_host, sizeof(amps_recc_burst_t) * (size_t)cfg->max_bursts) != hipSuccess) rc |= -ENOMEM;
+    // result records live in mapped, pinned host memory (zero copy: 728 B per burst over PCIe while the
+    // kernels run); h->records is the device-side view of the same allocation
+    if (hipHostMalloc((void **)&h->rec_host, sizeof(amps_recc_burst_t) * (size_t)cfg->max_bursts, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&h->records, h->rec_host, 0) != hipSuccess) rc |= -ENOMEM;
     if (hipHostMalloc((void **)&h->hdr_host, 2 * sizeof(uint32_t)) != hipSuccess) rc |= -ENOMEM;
     // IQ seam
     if (!rc && cfg->max_samples_per_push) {
@@ -409,7 +411,7 @@ void amps_recc_destroy(amps_recc_t *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     collect_spans(h);
     void *bufs[] = { h->carry[0], h->carry[1], h->gring, h->det, h->detcount, h->next_allowed, h->pending, h->capq,
-                     h->capq_count, h->records, h->nrecords, h->status, h->stage_iq, h->symbuf, h->sym_len, h->sym_cur,
+                     h->capq_count, h->nrecords, h->status, h->stage_iq, h->symbuf, h->sym_len, h->sym_cur,
                      h->sym_stage, h->bursts_dev, h->burst_chan_dev, h->nbursts_dev, h->dec_out_dev, h->dec_in_dev,
                      h->dec_chan_dev, h->dbg_d, h->dbg_S };
     for (void *p : bufs) if (p) (void)hipFree(p);
@@ -580,17 +582,15 @@ int amps_recc_drain(amps_recc_t *h, amps_recc_burst_t *out, size_t cap, size_t *
     if ((hdr[1] & (2u | 4u)) || n > h->cfg.max_bursts) { rc = -ENOSPC; }
     if (n > h->cfg.max_bursts) n = h->cfg.max_bursts;
     if (n) {
-        HIP_TRY(hipMemcpyAsync(h->rec_host, h->records, sizeof(amps_recc_burst_t) * n, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        // order by (channel, position) through an index sort: records are 728 bytes, keys are 16
-        std::vector<uint32_t> order(n);
-        for (uint32_t i = 0; i < n; i++) order[i] = i;
+        // the records are already in host memory (written by the capture kernel, visible after the sync above);
+        // order by (channel, position) through compact 16-byte keys, then gather once into the caller's buffer
+        struct Key { uint64_t k; uint32_t i; };
+        std::vector<Key> keys(n);
         const amps_recc_burst_t *r = h->rec_host;
-        std::sort(order.begin(), order.end(), [r](uint32_t x, uint32_t y) {
-            return r[x].channel != r[y].channel ? r[x].channel < r[y].channel : r[x].position < r[y].position;
-        });
+        for (uint32_t i = 0; i < n; i++) keys[i] = { ((uint64_t)r[i].channel << 40) | (r[i].position & ((1ull << 40) - 1)), i };
+        std::sort(keys.begin(), keys.end(), [](const Key &x, const Key &y) { return x.k < y.k; });
         size_t k = std::min<size_t>(n, cap);
-        if (out) for (size_t i = 0; i < k; i++) std::memcpy(&out[i], &r[order[i]], sizeof(amps_recc_burst_t));
+        if (out) for (size_t i = 0; i < k; i++) std::memcpy(&out[i], &r[keys[i].i], sizeof(amps_recc_burst_t));
         *nout = k;
         if (n > cap) rc = -ENOSPC;
     }
