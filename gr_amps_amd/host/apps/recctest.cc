@@ -1,0 +1,90 @@
+// recctest.cc -- config 0 plumbing: the message part of grc/recctest.grc (connections :3238-3274)
+// as a stand-alone program.  Modes:
+//   recctest syms <file.u8>  [chunk]   u8 0/1 symbol file -> amps.recc -> amps.recc_decode
+//   recctest iq   <file.fc32> [chunk]  200 ksps interleaved fc32 -> amps.recc_fused -> amps.recc_decode
+// Every message published on recc_decode's output ports is printed as one text line, which is what
+// tests/test_gpu_host_blocks.py compares with the oracle.
+#include <amps/recc.h>
+#include <amps/recc_decode.h>
+#include <amps/recc_fused.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iterator>
+#include <string>
+#include <vector>
+
+static std::string bits(const pmt::pmt_t &blob)
+{
+    std::string s;
+    const uint8_t *p = (const uint8_t *)pmt::blob_data(blob);
+    for (size_t i = 0; i < pmt::blob_length(blob); i++) s += p[i] ? '1' : '0';
+    return s;
+}
+
+namespace {
+struct sink : gr::block {   // prints what ampsbs.grc would route to focc / fvc / mutes / command_processor
+    sink() : gr::block("sink", gr::io_signature::make(0, 0, 0), gr::io_signature::make(0, 0, 0))
+    {
+        const char *ports[] = { "focc_words", "fvc_words", "audio_mute", "fvc_mute", "command_out" };
+        for (const char *p : ports) {
+            message_port_register_in(pmt::mp(p));
+            std::string name = p;
+            set_msg_handler(pmt::mp(p), [name](pmt::pmt_t m) {
+                if (name == "focc_words")
+                    std::printf("MSG focc_words stream=%ld n=%ld w1=%s w2=%s\n", pmt::to_long(pmt::tuple_ref(m, 0)), pmt::to_long(pmt::tuple_ref(m, 1)),
+                                bits(pmt::tuple_ref(m, 2)).c_str(), bits(pmt::tuple_ref(m, 3)).c_str());
+                else if (name == "fvc_words")
+                    std::printf("MSG fvc_words n=%ld w1=%s repeat=%llu\n", pmt::to_long(pmt::tuple_ref(m, 0)), bits(pmt::tuple_ref(m, 1)).c_str(),
+                                (unsigned long long)pmt::to_uint64(pmt::tuple_ref(m, 2)));
+                else if (name == "command_out") {
+                    size_t n = 0;
+                    const uint8_t *p = pmt::u8vector_elements(pmt::cdr(m), n);
+                    std::printf("MSG command_out %.*s\n", (int)n, (const char *)p);
+                } else
+                    std::printf("MSG %s %d\n", name.c_str(), pmt::to_bool(m) ? 1 : 0);
+            });
+        }
+    }
+    int general_work(int n, gr_vector_int &, gr_vector_const_void_star &, gr_vector_void_star &) override { return n; }
+};
+} // namespace
+
+int main(int argc, char **argv)
+{
+    if (argc < 3) { std::fprintf(stderr, "usage: %s syms|iq <file> [chunk]\n", argv[0]); return 2; }
+    const std::string mode = argv[1];
+    const int chunk = argc > 3 ? std::atoi(argv[3]) : 4096;
+    std::ifstream f(argv[2], std::ios::binary);
+    if (!f) { std::perror(argv[2]); return 2; }
+    std::vector<char> data((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    try {
+        auto dec = gr::amps::recc_decode::make();
+        auto snk = std::make_shared<sink>();
+        for (const char *p : { "focc_words", "fvc_words", "audio_mute", "fvc_mute", "command_out" }) gr::msg_connect(dec, p, snk, p);
+        gr_vector_void_star outs;
+        if (mode == "syms") {
+            auto src = gr::amps::recc::make();
+            gr::msg_connect(src, "bursts", dec, "bursts");
+            for (size_t off = 0; off < data.size(); off += (size_t)chunk) {
+                int n = (int)std::min<size_t>((size_t)chunk, data.size() - off);
+                gr_vector_const_void_star ins = { data.data() + off };
+                if (src->work(n, ins, outs) != 0) return 1;
+            }
+        } else {
+            auto src = gr::amps::recc_fused::make(10);
+            gr::msg_connect(src, "records", dec, "records");
+            const size_t ns = data.size() / 8;
+            for (size_t off = 0; off < ns; off += (size_t)chunk) {
+                int n = (int)std::min<size_t>((size_t)chunk, ns - off);
+                gr_vector_const_void_star ins = { data.data() + 8 * off };
+                if (src->work(n, ins, outs) != 0) return 1;
+            }
+        }
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "%s\n", e.what());
+        return 3;
+    }
+    return 0;
+}

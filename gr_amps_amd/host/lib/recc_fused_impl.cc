@@ -1,0 +1,57 @@
+// recc_fused_impl.cc -- gr::amps::recc_fused: complex baseband in, "bursts"-compatible messages out.
+// Replaces quadrature_demod_cf -> clock_recovery_mm_ff -> binary_slicer_fb -> amps_recc with the fused
+// MI355X kernel (amps_recc_push_iq / amps_recc_drain).
+#include <amps/recc_fused.h>
+#include <cstdio>
+#include <stdexcept>
+#include "amps_recc.h"
+
+namespace gr {
+namespace amps {
+
+class recc_fused_impl : public recc_fused {
+    amps_recc_t *d_handle;
+    static const int kMaxPush = 1 << 20;
+
+public:
+    explicit recc_fused_impl(int sps)
+        : gr::sync_block("recc_fused", gr::io_signature::make(1, 1, 2 * sizeof(float)), gr::io_signature::make(0, 0, 0)), d_handle(nullptr)
+    {
+        amps_recc_cfg_t cfg = {};
+        cfg.struct_size = sizeof(cfg);
+        cfg.n_channels = 1;
+        cfg.samples_per_symbol = (uint32_t)sps;
+        cfg.max_samples_per_push = kMaxPush;
+        cfg.max_bursts = 64;
+        cfg.device = -1;
+        int rc = amps_recc_create(&d_handle, &cfg);
+        if (rc != 0) throw std::runtime_error(std::string("amps::recc_fused: ") + amps_recc_strerror(rc));
+        message_port_register_out(pmt::mp("records"));
+    }
+    ~recc_fused_impl() { amps_recc_destroy(d_handle); }
+
+    int work(int noutput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &)
+    {
+        const float *in = (const float *)input_items[0];
+        int done = 0;
+        while (done < noutput_items) {
+            int n = noutput_items - done;
+            if (n > kMaxPush) n = kMaxPush;
+            int rc = amps_recc_push_iq(d_handle, in + 2 * (size_t)done, (size_t)n, (size_t)n, AMPS_MEM_HOST);
+            if (rc != 0) { std::fprintf(stderr, "amps::recc_fused: %s\n", amps_recc_strerror(rc)); return WORK_DONE; }
+            amps_recc_burst_t recs[64];
+            size_t nrec = 0;
+            rc = amps_recc_drain(d_handle, recs, 64, &nrec);
+            if (rc != 0) { std::fprintf(stderr, "amps::recc_fused: %s\n", amps_recc_strerror(rc)); return WORK_DONE; }
+            for (size_t i = 0; i < nrec; i++) message_port_pub(pmt::mp("records"), pmt::mp(&recs[i], sizeof(recs[i])));
+            done += n;
+        }
+        consume_each(noutput_items);
+        return 0;
+    }
+};
+
+recc_fused::sptr recc_fused::make(int samples_per_symbol) { return gnuradio::get_initial_sptr(new recc_fused_impl(samples_per_symbol)); }
+
+} // namespace amps
+} // namespace gr
