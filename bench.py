@@ -151,6 +151,14 @@ def main():
     total_syms = syms_per_step_rank * a.steps * world
     value = total_syms / el
     front_ms = tm["ms_front"] / max(1, tm["launches_front"])
+    traffic = None   # HBM bytes per launch from the PMC passes of the same command (profiles/rNN/traffic.json)
+    for tag in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
+        tj = os.path.join(ROOT, "profiles", tag, "traffic.json")
+        if os.path.exists(tj):
+            t = json.load(open(tj))
+            if t.get("algorithmic_bytes_per_launch") == C * N * 8:
+                traffic = t["hbm_bytes_per_launch"]
+            break
     ach = ALG_BYTES_PER_SYMBOL_DIRECT * syms_per_step_rank / (front_ms * 1e-3) / 1e9 if front_ms > 0 else 0.0
     out = {
         "metric": "AMPS RECC Manchester symbols demodulated+decoded per second (real-time channels = value/0.02)",
@@ -163,7 +171,7 @@ def main():
                    "realtime_channels_per_gpu": round(value / world / 20e3, 1),
                    "bursts_decoded_per_step_per_gpu": nrec // max(1, a.steps), "parallelism": "channels sharded x%d" % world},
         "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
                      "kernel": "recc_front_kernel<10>", "kernel_ms": round(front_ms, 4),
                      "frac_of_measured_copy_ceiling_6290": round(ach / 6290.0, 4),
                      "other_kernels_ms_per_step": {k: round(tm[k] / a.steps, 4) for k in ("ms_resolve", "ms_decode", "ms_carry")}},
