@@ -68,7 +68,7 @@ EXPORTS = (
     "amps_recc_abi_version", "amps_recc_strerror", "amps_recc_burst_size", "amps_recc_create",
     "amps_recc_destroy", "amps_recc_reset", "amps_recc_push_symbols", "amps_recc_decode_bursts",
     "amps_recc_push_iq", "amps_recc_push_wideband", "amps_recc_drain", "amps_recc_debug_demod",
-    "amps_recc_get_timing", "amps_recc_reply_words",
+    "amps_recc_get_timing", "amps_recc_reply_words", "amps_recc_debug_channelize",
 )
 
 _lib = None
@@ -106,6 +106,7 @@ def load():
     L.amps_recc_drain.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.amps_recc_debug_demod.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, vp, vp]
     L.amps_recc_get_timing.argtypes = [vp, C.POINTER(Timing), C.c_int]
+    L.amps_recc_debug_channelize.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.amps_recc_reply_words.argtypes = [vp, C.POINTER(Reply)]
     for name in EXPORTS:
         if name not in ("amps_recc_strerror", "amps_recc_burst_size", "amps_recc_destroy"):
@@ -234,6 +235,20 @@ class Recc:
         rc = load().amps_recc_push_wideband(self._h, ptr, n, mem)
         if rc:
             raise AmpsError(rc, "amps_recc_push_wideband")
+
+    def debug_channelize(self, iq):
+        """Channelizer only (test tap): wideband complex64 [n] -> complex64 [C][nframes]."""
+        if isinstance(iq, np.ndarray):
+            iq = np.ascontiguousarray(iq, np.complex64).reshape(-1)
+        n = iq.shape[0]
+        ptr, mem, keep = _as_ptr(iq)
+        cap = n // 512 + 2
+        out = np.zeros((self.n_channels, cap), np.complex64)
+        nf = C.c_size_t(0)
+        rc = load().amps_recc_debug_channelize(self._h, ptr, n, mem, _hostptr(out), cap, C.byref(nf))
+        if rc:
+            raise AmpsError(rc, "amps_recc_debug_channelize")
+        return out[:, :nf.value].copy()
 
     def drain(self, cap=None, copy=True):
         """Synchronise and return the decoded bursts since the last drain, sorted by (channel, position).

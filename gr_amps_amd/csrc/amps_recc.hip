@@ -642,6 +642,25 @@ done:
     return rc;
 }
 
+int amps_recc_debug_channelize(amps_recc_t *h, const float *iq, size_t nsamp, int mem, float *out, size_t out_ld, size_t *nframes)
+{
+    if (!h || !iq || !out || !nframes) return -EINVAL;
+    if (!h->chz.enabled) return -ENOSYS;
+    HIP_TRY(hipSetDevice(h->device));
+    const float2 *chan_iq = nullptr;
+    uint64_t ld = 0;
+    uint32_t nout = 0;
+    int rc = channelizer_run(h->chz, (const float2 *)iq, nsamp, mem, h->stream, &chan_iq, &ld, &nout);
+    if (rc) return rc;
+    *nframes = nout;
+    if (nout > out_ld) return -E2BIG;
+    if (nout)
+        HIP_TRY(hipMemcpy2DAsync(out, out_ld * sizeof(float2), chan_iq, ld * sizeof(float2), nout * sizeof(float2), h->C,
+                                 hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 int amps_recc_get_timing(amps_recc_t *h, amps_recc_timing_t *t, int reset)
 {
     if (!h || !t) return -EINVAL;

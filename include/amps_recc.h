@@ -16,7 +16,9 @@
  *                                   -> binary_slicer_fb -> amps_recc -> amps_recc_decode
  *                                   (grc/recctest.grc:458,846-874,807,310,349 and connections :3238-3274)
  *   amps_recc_push_wideband     <-  N x (freq_xlating_fir_filter_ccc -> the chain above), one per 30 kHz
- *                                   channel (grc/recctest.grc:889-937); polyphase channelizer front end
+ *                                   channel (grc/recctest.grc:889-937, taps :115-155); polyphase channelizer
+ *                                   front end: M = 1024 branches at fs = 30.72 Msps, D = 512 (60 ksps per
+ *                                   channel, samples_per_symbol = 3), 8 or 16 taps per branch
  *   amps_recc_reply_words       <-  handle_response / handle_registration / handle_origination
  *                                   lib/recc_decode_impl.cc:181-272 + word builders lib/amps_packet.cc:26-95
  *
@@ -173,6 +175,12 @@ int amps_recc_drain(amps_recc_t *h, amps_recc_burst_t *out, size_t cap, size_t *
  * channel for the last push_iq() call.  demod/soft/hard are host arrays of length n (may be NULL). */
 int amps_recc_debug_demod(amps_recc_t *h, const float *iq, size_t nsamp, int mem,
                           float *demod, float *soft, uint8_t *hard);
+
+/* test tap of the channelizer seam: channelise nsamp wideband samples (continuing the handle's wideband
+ * stream) WITHOUT running the RECC kernels; out is host memory [n_channels][out_ld] fc32, *nframes the
+ * number of output samples per channel produced. */
+int amps_recc_debug_channelize(amps_recc_t *h, const float *iq, size_t nsamp, int mem,
+                               float *out, size_t out_ld, size_t *nframes);
 
 int amps_recc_get_timing(amps_recc_t *h, amps_recc_timing_t *t, int reset);
 
