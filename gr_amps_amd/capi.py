@@ -50,6 +50,7 @@ class Timing(C.Structure):
         ("struct_size", C.c_uint32), ("launches_front", C.c_uint32), ("ms_front", C.c_double),
         ("ms_resolve", C.c_double), ("ms_decode", C.c_double), ("ms_carry", C.c_double),
         ("ms_symbols", C.c_double), ("samples_front", C.c_uint64),
+        ("ms_channelizer", C.c_double), ("launches_channelizer", C.c_uint32), ("_pad", C.c_uint32),
     ]
 
 
@@ -278,7 +279,7 @@ class Recc:
         rc = load().amps_recc_get_timing(self._h, C.byref(t), int(reset))
         if rc:
             raise AmpsError(rc, "amps_recc_get_timing")
-        return {k: getattr(t, k) for k, _ in Timing._fields_ if k != "struct_size"}
+        return {k: getattr(t, k) for k, _ in Timing._fields_ if k not in ("struct_size", "_pad")}
 
 
 def reply_words(rec):

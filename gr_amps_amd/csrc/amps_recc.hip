@@ -88,7 +88,7 @@ struct amps_recc {
     bool timing = false;
     std::vector<TimedSpan> spans;
     double ms[T_COUNT] = { 0 };
-    uint32_t launches_front = 0;
+    uint32_t launches_front = 0, launches_chz = 0;
     uint64_t samples_front = 0;
 
     // ---- debug taps (amps_recc_debug_demod) ----
@@ -127,7 +127,8 @@ void collect_spans(amps_recc *h)   // stream must be synchronised
         float t = 0.f;
         if (hipEventElapsedTime(&t, s.a, s.b) == hipSuccess) {
             h->ms[s.tag] += t;
-            if (s.tag == T_FRONT || s.tag == T_CHANNELIZER) { h->launches_front++; h->samples_front += s.samples; }
+            if (s.tag == T_FRONT) { h->launches_front++; h->samples_front += s.samples; }
+            if (s.tag == T_CHANNELIZER) h->launches_chz++;
         }
         (void)hipEventDestroy(s.a);
         (void)hipEventDestroy(s.b);
@@ -670,7 +671,9 @@ int amps_recc_get_timing(amps_recc_t *h, amps_recc_timing_t *t, int reset)
     std::memset(t, 0, sizeof(*t));
     t->struct_size = sizeof(*t);
     t->launches_front = h->launches_front;
-    t->ms_front = h->ms[T_FRONT] + h->ms[T_CHANNELIZER];
+    t->ms_front = h->ms[T_FRONT];
+    t->ms_channelizer = h->ms[T_CHANNELIZER];
+    t->launches_channelizer = h->launches_chz;
     t->ms_resolve = h->ms[T_RESOLVE];
     t->ms_decode = h->ms[T_DECODE];
     t->ms_carry = h->ms[T_CARRY];
@@ -679,6 +682,7 @@ int amps_recc_get_timing(amps_recc_t *h, amps_recc_timing_t *t, int reset)
     if (reset) {
         for (double &m : h->ms) m = 0;
         h->launches_front = 0;
+        h->launches_chz = 0;
         h->samples_front = 0;
     }
     return 0;

@@ -131,6 +131,9 @@ typedef struct amps_recc_timing {
     double   ms_carry;         /* inter-push halo copy kernel                                             */
     double   ms_symbols;       /* symbol-seam work() kernel                                               */
     uint64_t samples_front;    /* per-channel IQ samples consumed by the timed front launches             */
+    double   ms_channelizer;   /* polyphase channelizer kernel (wideband seam)                            */
+    uint32_t launches_channelizer;
+    uint32_t _pad;
 } amps_recc_timing_t;
 
 typedef struct amps_recc amps_recc_t; /* opaque; owns device buffers + per-channel stream state */
