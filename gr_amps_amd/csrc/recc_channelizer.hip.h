@@ -12,11 +12,13 @@
 // prototype h and decimated by D = M/2 (2x oversampled: 60 ksps = 3 samples per Manchester symbol at M = 1024).
 //
 // Mapping to the hardware (one 256-thread workgroup walks a run of consecutive frames):
-//   * the last L input samples live in an LDS ring (sample n at slot n mod L: 64 KiB for P = 8); a frame
-//     adds D = 512 new samples with one coalesced 4 KiB read (the next frame's are prefetched in registers);
-//   * thread t folds the four outputs t' = t + 256 j: because it takes r = (t' + n0) mod M the tap indices
-//     are always {t' + qM}, so its 4P coefficients stay in registers for the whole kernel and only the ring
-//     address rotates; one v_pk_fma per tap (complex sample x real coefficient);
+//   * polyphase delay lines live in REGISTERS: thread t owns the four branches with residue t + 256 jb (mod M).
+//     A frame adds D = 512 new samples, read with one coalesced 4 KiB load (prefetched one frame ahead), and the
+//     two samples a thread loads are exactly the ones its own branches need -- there is no LDS sample window at
+//     all (a first version kept a 64 KiB LDS ring: 80 KiB per workgroup, two workgroups per CU, 32 LDS reads and
+//     64 address instructions per thread per frame);
+//   * the fold is one v_pk_fma per tap against 4P register-resident coefficients; which coefficient set a branch
+//     uses alternates with the frame parity, so the frame loop is unrolled by two parities (by eight, see below);
 //   * FFT-1024 = five radix-4 Stockham passes; pass 1 runs on the registers the fold just produced, passes
 //     2-4 exchange through two 8 KiB LDS buffers, pass 5 leaves bins {t, t+256, t+512, t+768} in registers --
 //     so a thread owns the same four channels in every frame.  Twiddles are per-thread constants, computed
@@ -58,23 +60,69 @@ typedef float cf2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ cf2 cmul(cf2 a, cf2 b) { return (cf2){ a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x }; }
 __device__ __forceinline__ cf2 mul_mi(cf2 a) { return (cf2){ a.y, -a.x }; }   // a * (-i)
 
+// One frame of the filter bank for the thread's four branches (residues t + 256*jb).  PAR = parity of the
+// absolute frame index m: the two samples the thread just loaded belong to branches {0,1} (m even) or {2,3}
+// (m odd), and the fold of branch jb uses the coefficient set jb ^ 2 when (m+1) is odd -- all register indices
+// are compile-time constants.
+template <int P, int PAR>
+__device__ __forceinline__ void chz_frame(cf2 (&line)[4][P], const float (&coef)[4][P], const cf2 (&tw)[4][3],
+                                          cf2 n0, cf2 n1, cf2 *bufA, cf2 *bufB, int t, cf2 (&y)[4])
+{
+    // ---- delay lines: shift in the two new samples (branch PAR*2 and PAR*2+1)
+#pragma unroll
+    for (int q = 0; q + 1 < P; q++) { line[2 * PAR][q] = line[2 * PAR][q + 1]; line[2 * PAR + 1][q] = line[2 * PAR + 1][q + 1]; }
+    line[2 * PAR][P - 1] = n0;
+    line[2 * PAR + 1][P - 1] = n1;
+    // ---- fold: x[jb] = sum_q h[t + 256 j + qM] * line[jb][q],  j = jb ^ (2 * ((m+1) & 1))
+    constexpr int SW = 2 * ((PAR + 1) & 1);
+    cf2 x[4];
+#pragma unroll
+    for (int jb = 0; jb < 4; jb++) {
+        cf2 s = { 0.f, 0.f };
+#pragma unroll
+        for (int q = 0; q < P; q++) s = __builtin_elementwise_fma(line[jb][q], (cf2){ coef[jb ^ SW][q], coef[jb ^ SW][q] }, s);
+        x[jb] = s;
+    }
+    // ---- FFT-1024, radix-4 Stockham.  pass 1 (Ns = 1): registers -> bufA[4t .. 4t+3]
+    {
+        cf2 v0 = x[0] + x[2], v1 = x[0] - x[2], v2 = x[1] + x[3], v3 = mul_mi(x[1] - x[3]);
+        bufA[4 * t + 0] = v0 + v2; bufA[4 * t + 1] = v1 + v3; bufA[4 * t + 2] = v0 - v2; bufA[4 * t + 3] = v1 - v3;
+    }
+    __syncthreads();
+    // passes 2..4 through LDS, pass 5 into registers (bins t, t+256, t+512, t+768)
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const int Ns = 4 << (2 * p);
+        const cf2 *src = (p & 1) ? bufB : bufA;
+        cf2 *dst = (p & 1) ? bufA : bufB;
+        cf2 a0 = src[t], a1 = cmul(src[t + 256], tw[p][0]), a2 = cmul(src[t + 512], tw[p][1]), a3 = cmul(src[t + 768], tw[p][2]);
+        cf2 v0 = a0 + a2, v1 = a0 - a2, v2 = a1 + a3, v3 = mul_mi(a1 - a3);
+        y[0] = v0 + v2; y[1] = v1 + v3; y[2] = v0 - v2; y[3] = v1 - v3;
+        if (p < 3) {
+            const int k = t & (Ns - 1);
+            const int i = ((t - k) << 2) + k;
+            dst[i] = y[0]; dst[i + Ns] = y[1]; dst[i + 2 * Ns] = y[2]; dst[i + 3 * Ns] = y[3];
+            __syncthreads();
+        }
+    }
+}
+
 template <int P>
 __global__ __launch_bounds__(256) void chz_pfb_fft_kernel(ChzArgs a)
 {
     constexpr int M = CHZ_M, D = CHZ_D, L = P * M;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    cf2 *ring = (cf2 *)smem;                 // [L]
-    cf2 *bufA = ring + L;                    // [M]
-    cf2 *bufB = bufA + M;                    // [M]
+    __shared__ cf2 bufA[CHZ_M];
+    __shared__ cf2 bufB[CHZ_M];
     const int t = threadIdx.x;
-    const uint32_t f0 = blockIdx.x * a.frames_per_wg;          // first frame of this workgroup (launch-relative)
+    const uint32_t f0 = blockIdx.x * a.frames_per_wg;          // first frame of this workgroup (launch-relative, multiple of 8)
     if (f0 >= a.nframes) return;
     uint32_t f1 = f0 + a.frames_per_wg; if (f1 > a.nframes) f1 = a.nframes;
 
     // virtual input stream of this launch: index v in [-(L-D), nsamp + leftover): carry then block.
-    // frame f (launch-relative) consumes v in [f*D - (L-D), f*D + D)
+    // frame f (launch-relative) consumes v in [f*D - (L-D), f*D + D); the absolute frame index of f = 0 is even
+    // (the host only ever consumes an even number of frames), so parity(m) = parity(f) and residue(v) = v mod M.
     const int64_t hist = (int64_t)L - D;
-    const int64_t lead = (int64_t)a.carry_len - hist;          // leftover samples (< D) that precede the block
+    const int64_t lead = (int64_t)a.carry_len - hist;          // leftover samples (< 2D) that precede the block
     auto fetch = [&](int64_t v) -> cf2 {
         int64_t ci = v + hist;                                  // index into carry
         if (ci < 0) return (cf2){ 0.f, 0.f };
@@ -84,7 +132,7 @@ __global__ __launch_bounds__(256) void chz_pfb_fft_kernel(ChzArgs a)
         return (cf2){ s.x, s.y };
     };
 
-    // coefficients h[t' + qM] for t' = t + 256 j
+    // coefficients h[t + 256 j + qM]
     float coef[4][P];
 #pragma unroll
     for (int j = 0; j < 4; j++)
@@ -102,91 +150,50 @@ __global__ __launch_bounds__(256) void chz_pfb_fft_kernel(ChzArgs a)
         tw[p][1] = cmul(tw[p][0], tw[p][0]);
         tw[p][2] = cmul(tw[p][1], tw[p][0]);
     }
+    // delay lines: branch jb (residue r = t + 256 jb) holds its P most recent samples before frame f0:
+    // v_last = largest v < f0*D with v mod M == r   (f0*D is a multiple of M because f0 is even)
+    cf2 line[4][P];
+    {
+        const int64_t vend = (int64_t)f0 * D;
+#pragma unroll
+        for (int jb = 0; jb < 4; jb++) {
+            const int64_t vlast = vend - M + (t + 256 * jb);
+#pragma unroll
+            for (int q = 0; q < P; q++) line[jb][q] = fetch(vlast - (int64_t)M * (P - 1 - q));
+        }
+    }
 
-    // ring slot of launch-relative sample v: (v + base) mod L, base chosen so that slots line up with
-    // n mod L of the absolute stream only up to a constant -- what matters is n mod M, tracked by parity below
-    auto slot = [&](int64_t v) -> int { return (int)((v + (int64_t)L * 4) & (L - 1)); };
-    // prologue: history of the first frame
-    for (int64_t v = (int64_t)f0 * D - hist + t; v < (int64_t)f0 * D; v += 256) ring[slot(v)] = fetch(v);
+    // eight frames of this thread's four bins stay in registers and leave as 64-byte runs of the channel-major output
     cf2 nx0 = fetch((int64_t)f0 * D + t), nx1 = fetch((int64_t)f0 * D + 256 + t);
-
-    cf2 acc[CHZ_GROUP][4] = {};
-    for (uint32_t f = f0; f < f1; f++) {
-        const int64_t vs = (int64_t)f * D;                      // first new sample of this frame
-        ring[slot(vs + t)] = nx0;
-        ring[slot(vs + 256 + t)] = nx1;
-        if (f + 1 < f1) { nx0 = fetch(vs + D + t); nx1 = fetch(vs + D + 256 + t); }
-        __syncthreads();
-        // ---- fold: window = v in [vs + D - L, vs + D); tap i <-> v = vs + D - L + i; thread's taps i = t' + qM
-        cf2 u[4];
-        const int wbase = slot(vs + D - L);                     // ring slot of tap 0
+    for (uint32_t fg = f0; fg < f1; fg += CHZ_GROUP) {
+        cf2 acc[CHZ_GROUP][4];
+        const int ng = (int)(f1 - fg < (uint32_t)CHZ_GROUP ? f1 - fg : (uint32_t)CHZ_GROUP);
+#pragma unroll
+        for (int g = 0; g < CHZ_GROUP; g++) {
+            if (g < ng) {
+                const cf2 c0 = nx0, c1 = nx1;
+                const int64_t vn = (int64_t)(fg + g + 1) * D;             // next frame's samples (zero beyond the data)
+                nx0 = fetch(vn + t); nx1 = fetch(vn + 256 + t);
+                if (g & 1) chz_frame<P, 1>(line, coef, tw, c0, c1, bufA, bufB, t, acc[g]);
+                else chz_frame<P, 0>(line, coef, tw, c0, c1, bufA, bufB, t, acc[g]);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            cf2 s = { 0.f, 0.f };
-            const int b = wbase + t + 256 * j;
+            const uint32_t ch = ((uint32_t)(t + 256 * j) - a.first_bin) & (M - 1);
+            if (ch < a.n_channels) {
+                float2 *dstp = a.out + (uint64_t)ch * a.ld + fg;
+                if (ng == CHZ_GROUP) {
 #pragma unroll
-            for (int q = 0; q < P; q++) {
-                const cf2 x = ring[(b + q * M) & (L - 1)];
-                s = __builtin_elementwise_fma(x, (cf2){ coef[j][q], coef[j][q] }, s);
-            }
-            u[j] = s;
-        }
-        // FFT input index r = (n0 + t') mod M: n0 mod M alternates 0 / M/2 with the absolute frame parity
-        // (n0 = (m+1) D - L, L multiple of M, D = M/2), so odd (m+1) swaps the halves: j <-> j ^ 2
-        const bool half = ((a.odd_start + f + 1) & 1) != 0;
-        cf2 x0 = half ? u[2] : u[0], x1 = half ? u[3] : u[1], x2 = half ? u[0] : u[2], x3 = half ? u[1] : u[3];
-        // ---- pass 1 (Ns = 1): registers -> bufA[4t .. 4t+3]
-        {
-            cf2 v0 = x0 + x2, v1 = x0 - x2, v2 = x1 + x3, v3 = mul_mi(x1 - x3);
-            bufA[4 * t + 0] = v0 + v2; bufA[4 * t + 1] = v1 + v3; bufA[4 * t + 2] = v0 - v2; bufA[4 * t + 3] = v1 - v3;
-        }
-        __syncthreads();
-        // ---- passes 2..4 through LDS, pass 5 into registers
-        cf2 y0, y1, y2, y3;
+                    for (int e = 0; e < CHZ_GROUP; e += 2)
+                        *(float4 *)(dstp + e) = make_float4(acc[e][j].x, acc[e][j].y, acc[e + 1][j].x, acc[e + 1][j].y);
+                } else {
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const int Ns = 4 << (2 * p);
-            const cf2 *src = (p & 1) ? bufB : bufA;
-            cf2 *dst = (p & 1) ? bufA : bufB;
-            cf2 a0 = src[t], a1 = cmul(src[t + 256], tw[p][0]), a2 = cmul(src[t + 512], tw[p][1]), a3 = cmul(src[t + 768], tw[p][2]);
-            cf2 v0 = a0 + a2, v1 = a0 - a2, v2 = a1 + a3, v3 = mul_mi(a1 - a3);
-            y0 = v0 + v2; y1 = v1 + v3; y2 = v0 - v2; y3 = v1 - v3;
-            if (p < 3) {
-                const int k = t & (Ns - 1);
-                const int i = ((t - k) << 2) + k;
-                dst[i] = y0; dst[i + Ns] = y1; dst[i + 2 * Ns] = y2; dst[i + 3 * Ns] = y3;
-                __syncthreads();
-            }
-        }
-        // bins t, t+256, t+512, t+768 of this frame: shift them into the 8-frame register window
-        // (static register indices only; a dynamically indexed array would live in scratch)
-#pragma unroll
-        for (int e = 0; e + 1 < CHZ_GROUP; e++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc[e][j] = acc[e + 1][j];
-        acc[CHZ_GROUP - 1][0] = y0; acc[CHZ_GROUP - 1][1] = y1; acc[CHZ_GROUP - 1][2] = y2; acc[CHZ_GROUP - 1][3] = y3;
-        const int g = (int)((f - f0) & (CHZ_GROUP - 1));        // frames held = g + 1, newest at acc[7]
-        if (g == CHZ_GROUP - 1 || f + 1 == f1) {
-            const uint32_t fbase = f - g;                       // first frame of the group (multiple of 8, launch-relative)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t ch = ((uint32_t)(t + 256 * j) - a.first_bin) & (M - 1);
-                if (ch < a.n_channels) {
-                    float2 *dstp = a.out + (uint64_t)ch * a.ld + fbase;
-                    if (g == CHZ_GROUP - 1) {
-#pragma unroll
-                        for (int e = 0; e < CHZ_GROUP; e += 2)
-                            *(float4 *)(dstp + e) = make_float4(acc[e][j].x, acc[e][j].y, acc[e + 1][j].x, acc[e + 1][j].y);
-                    } else {                                     // tail of the workgroup's run: frames sit at acc[7-g .. 7]
-#pragma unroll
-                        for (int e = 0; e < CHZ_GROUP; e++)
-                            if (e >= CHZ_GROUP - 1 - g) dstp[e - (CHZ_GROUP - 1 - g)] = make_float2(acc[e][j].x, acc[e][j].y);
-                    }
+                    for (int e = 0; e < CHZ_GROUP; e++)
+                        if (e < ng) dstp[e] = make_float2(acc[e][j].x, acc[e][j].y);
                 }
             }
         }
-        // the ring slots this frame read are rewritten next frame only after the barriers above; bufA/bufB are
-        // rewritten after the next frame's first barrier
     }
 }
 
@@ -256,7 +263,7 @@ inline std::vector<float> chz_design_taps(int P)
 inline int channelizer_reset(ChannelizerState &z, hipStream_t s)
 {
     if (!z.enabled) return 0;
-    const size_t cap = (size_t)z.P * CHZ_M;   // hist + leftover < L
+    const size_t cap = (size_t)z.P * CHZ_M + CHZ_D;   // hist + leftover (< 2D)
     if (hipMemsetAsync(z.carry[0], 0, sizeof(float2) * cap, s) != hipSuccess) return -EIO;
     if (hipMemsetAsync(z.carry[1], 0, sizeof(float2) * cap, s) != hipSuccess) return -EIO;
     z.carry_cur = 0;
@@ -285,8 +292,8 @@ inline int channelizer_create(ChannelizerState &z, const amps_recc_cfg_t &cfg, h
     std::vector<float> h = chz_design_taps(P);
     if (hipMalloc((void **)&z.taps, sizeof(float) * L) != hipSuccess) return -ENOMEM;
     if (hipMemcpy(z.taps, h.data(), sizeof(float) * L, hipMemcpyHostToDevice) != hipSuccess) return -EIO;
-    if (hipMalloc((void **)&z.carry[0], sizeof(float2) * L) != hipSuccess) return -ENOMEM;
-    if (hipMalloc((void **)&z.carry[1], sizeof(float2) * L) != hipSuccess) return -ENOMEM;
+    if (hipMalloc((void **)&z.carry[0], sizeof(float2) * (L + CHZ_D)) != hipSuccess) return -ENOMEM;
+    if (hipMalloc((void **)&z.carry[1], sizeof(float2) * (L + CHZ_D)) != hipSuccess) return -ENOMEM;
     if (hipMalloc((void **)&z.out, sizeof(float2) * (size_t)z.C * z.ld) != hipSuccess) return -ENOMEM;
     z.enabled = true;
     (void)s;
@@ -312,7 +319,7 @@ inline int channelizer_run(ChannelizerState &z, const float2 *iq, size_t nsamp, 
     const uint32_t L = (uint32_t)z.P * CHZ_M, hist = L - CHZ_D;
     const uint32_t leftover = z.carry_len - hist;
     const uint64_t avail = (uint64_t)leftover + nsamp;
-    const uint32_t nframes = (uint32_t)(avail / CHZ_D);
+    const uint32_t nframes = (uint32_t)(avail / CHZ_D) & ~1u;    // even: keeps the absolute frame parity of every launch at 0
     if (nframes > z.max_frames) return -E2BIG;
     if (nframes) {
         ChzArgs a{};
@@ -322,16 +329,10 @@ inline int channelizer_run(ChannelizerState &z, const float2 *iq, size_t nsamp, 
         fpw = std::max<uint32_t>(64, fpw);                            // history refill = 2P-1 frames per workgroup
         fpw = (fpw + CHZ_GROUP - 1) / CHZ_GROUP * CHZ_GROUP;
         a.frames_per_wg = fpw; a.first_bin = z.first_bin; a.n_channels = z.C;
-        a.odd_start = (uint32_t)(z.frames_done & 1);
+        a.odd_start = 0;
         const uint32_t nwg = (nframes + fpw - 1) / fpw;
-        const size_t lds = sizeof(float2) * ((size_t)L + 2 * CHZ_M);
-        if (z.P == 8) {
-            (void)hipFuncSetAttribute((const void *)chz_pfb_fft_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(chz_pfb_fft_kernel<8>, dim3(nwg), dim3(256), lds, s, a);
-        } else {
-            (void)hipFuncSetAttribute((const void *)chz_pfb_fft_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(chz_pfb_fft_kernel<16>, dim3(nwg), dim3(256), lds, s, a);
-        }
+        if (z.P == 8) hipLaunchKernelGGL(chz_pfb_fft_kernel<8>, dim3(nwg), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(chz_pfb_fft_kernel<16>, dim3(nwg), dim3(256), 0, s, a);
     }
     const uint32_t consumed = nframes * CHZ_D;                        // virtual samples consumed (incl. leftover)
     const uint32_t new_left = (uint32_t)(avail - consumed);

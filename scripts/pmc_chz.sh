@@ -1,0 +1,12 @@
+#!/bin/bash
+TAG=${1:-chz}
+OUT=$PWD/gpurun_out/pmc_$TAG
+mkdir -p $OUT
+R=$PWD
+cd /tmp && export TMPDIR=/tmp
+SHORT="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --secondary none"
+rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmc1 -o pmc -- $SHORT > $OUT/pmc1.log 2>&1
+rocprofv3 --output-format csv --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE -d $OUT/pmc2 -o pmc -- $SHORT > $OUT/pmc2.log 2>&1
+rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $SHORT > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $SHORT > $OUT/pmc_write.log 2>&1
+for k in chz_pfb recc_front; do echo "== $k"; python $R/scripts/pmc_summary.py $OUT $k; done
