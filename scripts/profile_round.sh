@@ -1,20 +1,18 @@
 #!/bin/bash
-# rocprofv3 evidence for one round: kernel-trace stats (committed under profiles/) and PMC passes.
-# usage: scripts/profile_round.sh <tag>     (run on the GPU box from the repo root)
+# rocprofv3 evidence for one round: kernel-trace stats of the default bench command and separate PMC passes.
+# usage (GPU box, repo root): scripts/profile_round.sh <tag>      -> gpurun_out/prof_<tag>/
 TAG=${1:-r01}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
+R=$PWD
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
-BENCH="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+BENCH="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline"          # wideband832 + secondary direct832
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
 SHORT="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmc1 -o pmc -- $SHORT > $OUT/pmc1.log 2>&1
-rocprofv3 --output-format csv --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM -d $OUT/pmc2 -o pmc -- $SHORT > $OUT/pmc2.log 2>&1
+rocprofv3 --output-format csv --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU GRBM_GUI_ACTIVE -d $OUT/pmc2 -o pmc -- $SHORT > $OUT/pmc2.log 2>&1
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $SHORT > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $SHORT > $OUT/pmc_write.log 2>&1
-rocprofv3 --output-format csv --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_l2 -o pmc -- $SHORT > $OUT/pmc_l2.log 2>&1
-find $OUT -name "*.csv" | head -30
-# keep the payload small: drop anything that is not a csv/log
 find $OUT -type f ! -name "*.csv" ! -name "*.log" -delete
+for k in chz_pfb recc_front_kernel; do echo "== $k"; python $R/scripts/pmc_summary.py $OUT $k; done
 du -sh $OUT
