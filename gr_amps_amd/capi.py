@@ -16,6 +16,7 @@ CAPTURE = 3374
 MAX_WORK_ITEMS = 61439
 MEM_HOST, MEM_DEVICE = 0, 1
 FLAG_TIME_KERNELS = 1
+FLAG_MAJORITY = 2
 
 MSG_CLASSES = ("invalid_word_a", "e_zero", "page_response", "registration", "origination", "bad_nawc", "unknown")
 
@@ -70,6 +71,7 @@ EXPORTS = (
     "amps_recc_destroy", "amps_recc_reset", "amps_recc_push_symbols", "amps_recc_decode_bursts",
     "amps_recc_push_iq", "amps_recc_push_wideband", "amps_recc_drain", "amps_recc_debug_demod",
     "amps_recc_get_timing", "amps_recc_reply_words", "amps_recc_debug_channelize",
+    "amps_bch_encode_words", "amps_bch_decode_words",
 )
 
 _lib = None
@@ -109,8 +111,10 @@ def load():
     L.amps_recc_get_timing.argtypes = [vp, C.POINTER(Timing), C.c_int]
     L.amps_recc_debug_channelize.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.amps_recc_reply_words.argtypes = [vp, C.POINTER(Reply)]
+    L.amps_bch_encode_words.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, vp]
+    L.amps_bch_decode_words.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, vp, vp, vp]
     for name in EXPORTS:
-        if name not in ("amps_recc_strerror", "amps_recc_burst_size", "amps_recc_destroy"):
+        if name not in ("amps_recc_strerror", "amps_recc_burst_size", "amps_recc_destroy"):   # every other entry point returns int
             getattr(L, name).restype = C.c_int
     if L.amps_recc_burst_size() != BURST_DTYPE.itemsize:
         raise ImportError("amps_recc_burst_t layout mismatch between binding and library")
@@ -138,7 +142,7 @@ class Recc:
     """One handle = `n_channels` independent RECC receivers on one MI355X."""
 
     def __init__(self, n_channels=1, sps=10, max_samples=0, max_bursts=1024, device=-1, time_kernels=False,
-                 stream=None, wideband=None):
+                 stream=None, wideband=None, majority=False):
         L = load()
         cfg = Cfg()
         cfg.struct_size = C.sizeof(Cfg)
@@ -147,7 +151,7 @@ class Recc:
         cfg.max_samples_per_push = max_samples
         cfg.max_bursts = max_bursts
         cfg.device = device
-        cfg.flags = FLAG_TIME_KERNELS if time_kernels else 0
+        cfg.flags = (FLAG_TIME_KERNELS if time_kernels else 0) | (FLAG_MAJORITY if majority else 0)
         cfg.stream = stream
         if wideband:
             cfg.wideband_channels = wideband["channels"]
@@ -236,6 +240,27 @@ class Recc:
         rc = load().amps_recc_push_wideband(self._h, ptr, n, mem)
         if rc:
             raise AmpsError(rc, "amps_recc_push_wideband")
+
+    def bch_encode(self, msg_bits):
+        """uint8 [n][k] message bits -> uint8 [n][k+12] code words (k = 28: FOCC/FVC, k = 36: RECC)."""
+        m = np.ascontiguousarray(msg_bits, np.uint8)
+        n, k = m.shape
+        out = np.zeros((n, k + 12), np.uint8)
+        rc = load().amps_bch_encode_words(self._h, _hostptr(m), n, k, MEM_HOST, _hostptr(out))
+        if rc:
+            raise AmpsError(rc, "amps_bch_encode_words")
+        return out
+
+    def bch_decode(self, codewords):
+        """uint8 [n][k+12] -> (msg uint8 [n][k], valid uint8 [n], nerrors uint8 [n])."""
+        c = np.ascontiguousarray(codewords, np.uint8)
+        n, nb = c.shape
+        k = nb - 12
+        msg, valid, nerr = np.zeros((n, k), np.uint8), np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+        rc = load().amps_bch_decode_words(self._h, _hostptr(c), n, k, MEM_HOST, _hostptr(msg), _hostptr(valid), _hostptr(nerr))
+        if rc:
+            raise AmpsError(rc, "amps_bch_decode_words")
+        return msg, valid, nerr
 
     def debug_channelize(self, iq):
         """Channelizer only (test tap): wideband complex64 [n] -> complex64 [C][nframes]."""

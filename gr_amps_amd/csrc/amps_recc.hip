@@ -295,6 +295,7 @@ int run_iq_device(amps_recc *h, const float2 *iq, uint64_t ld, uint32_t nsamp)
         ca.capq = h->capq; ca.capq_count = h->capq_count; ca.capq_cap = h->cfg.max_bursts; ca.sps = h->sps;
         ca.gring = h->gring; ca.ring_mask = h->ring_words - 1; ca.ring_words = h->ring_words;
         ca.records = h->records; ca.nrecords = h->nrecords; ca.rec_cap = h->cfg.max_bursts; ca.status = h->status;
+        ca.majority = (h->cfg.flags & AMPS_RECC_FLAG_MAJORITY) ? 1u : 0u;
         {
             SpanGuard g(h, T_DECODE);
             uint32_t grid = std::min<uint32_t>(h->cfg.max_bursts, 2048u);
@@ -512,7 +513,8 @@ int amps_recc_decode_bursts(amps_recc_t *h, const uint8_t *bursts, size_t nburst
     {
         SpanGuard g(h, T_DECODE);
         uint32_t grid = (uint32_t)std::min<size_t>(nbursts, 4096);
-        hipLaunchKernelGGL(recc_decode_bursts_kernel, dim3(grid), dim3(64), 0, s, din, dchan, (uint32_t)nbursts, h->dec_out_dev);
+        hipLaunchKernelGGL(recc_decode_bursts_kernel, dim3(grid), dim3(64), 0, s, din, dchan, (uint32_t)nbursts, h->dec_out_dev,
+                           (h->cfg.flags & AMPS_RECC_FLAG_MAJORITY) ? 1u : 0u);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, h->dec_out_dev, nbursts * sizeof(amps_recc_burst_t), hipMemcpyDeviceToHost, s));
@@ -686,6 +688,61 @@ int amps_recc_get_timing(amps_recc_t *h, amps_recc_timing_t *t, int reset)
         h->samples_front = 0;
     }
     return 0;
+}
+
+// ---- BCH(63,51) shortened: batch encode / decode on the device
+static int bch_io(amps_recc_t *h, const uint8_t *in, size_t nin, int mem, uint8_t **din)
+{
+    *din = nullptr;
+    if (mem == AMPS_MEM_DEVICE) { *din = const_cast<uint8_t *>(in); return 0; }
+    if (hipMalloc((void **)din, nin ? nin : 1) != hipSuccess) return -ENOMEM;
+    if (hipMemcpyAsync(*din, in, nin, hipMemcpyHostToDevice, h->stream) != hipSuccess) { (void)hipFree(*din); return -EIO; }
+    return 0;
+}
+
+int amps_bch_encode_words(amps_recc_t *h, const uint8_t *msg, size_t nwords, int k, int mem, uint8_t *codewords)
+{
+    if (!h || k < 1 || k > 51 || (nwords && (!msg || !codewords))) return -EINVAL;
+    if (nwords == 0) return 0;
+    HIP_TRY(hipSetDevice(h->device));
+    uint8_t *din = nullptr, *dout = nullptr;
+    int rc = bch_io(h, msg, nwords * k, mem, &din);
+    if (rc) return rc;
+    const size_t nout = nwords * (size_t)(k + 12);
+    if (hipMalloc((void **)&dout, nout) != hipSuccess) rc = -ENOMEM;
+    if (!rc) {
+        hipLaunchKernelGGL(bch_encode_words_kernel, dim3((unsigned)std::min<size_t>((nwords + 255) / 256, 4096)), dim3(256), 0, h->stream,
+                           din, (uint32_t)nwords, k, dout);
+        if (hipMemcpyAsync(codewords, dout, nout, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) rc = -EIO;
+    }
+    if (mem != AMPS_MEM_DEVICE && din) (void)hipFree(din);
+    if (dout) (void)hipFree(dout);
+    return rc;
+}
+
+int amps_bch_decode_words(amps_recc_t *h, const uint8_t *codewords, size_t nwords, int k, int mem, uint8_t *msg, uint8_t *valid, uint8_t *nerrors)
+{
+    if (!h || k < 1 || k > 51 || (nwords && (!codewords || !msg || !valid))) return -EINVAL;
+    if (nwords == 0) return 0;
+    HIP_TRY(hipSetDevice(h->device));
+    uint8_t *din = nullptr, *dmsg = nullptr, *dval = nullptr, *derr = nullptr;
+    int rc = bch_io(h, codewords, nwords * (size_t)(k + 12), mem, &din);
+    if (rc) return rc;
+    if (hipMalloc((void **)&dmsg, nwords * k) != hipSuccess || hipMalloc((void **)&dval, nwords) != hipSuccess ||
+        hipMalloc((void **)&derr, nwords) != hipSuccess) rc = -ENOMEM;
+    if (!rc) {
+        hipLaunchKernelGGL(bch_decode_words_kernel, dim3((unsigned)std::min<size_t>((nwords + 255) / 256, 4096)), dim3(256), 0, h->stream,
+                           din, (uint32_t)nwords, k, dmsg, dval, derr);
+        bool bad = hipMemcpyAsync(msg, dmsg, nwords * k, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                   hipMemcpyAsync(valid, dval, nwords, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                   (nerrors && hipMemcpyAsync(nerrors, derr, nwords, hipMemcpyDeviceToHost, h->stream) != hipSuccess) ||
+                   hipStreamSynchronize(h->stream) != hipSuccess;
+        if (bad) rc = -EIO;
+    }
+    if (mem != AMPS_MEM_DEVICE && din) (void)hipFree(din);
+    for (uint8_t *p : { dmsg, dval, derr }) if (p) (void)hipFree(p);
+    return rc;
 }
 
 // ---- reply generation: handle_response / handle_registration / handle_origination

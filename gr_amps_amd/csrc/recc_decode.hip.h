@@ -60,18 +60,18 @@ struct BchResult {
     int e[3];
 };
 
-// bits: 48 bytes (0/1), bit i is the coefficient of x^(47-i); the 15 shortening zeros sit at x^48..x^62.
+// bits: nbits bytes (0/1), bit i is the coefficient of x^(nbits-1-i); the shortening zeros sit above x^(nbits-1).
 // Semantics = IT++ BCH(63,2,true)::decode: syndromes, two Berlekamp steps (closed form for t = 2),
 // root search over all 63 positions, failure iff #roots != deg(Lambda).  Roots in the 15 padding
 // positions are NOT rejected (the reference does not check them).
-__device__ inline BchResult bch4836_decode(const uint8_t *bits)
+__device__ inline BchResult bch_short_decode(const uint8_t *bits, int nbits)
 {
     BchResult r;
     r.ok = 0; r.nflip = 0; r.e[0] = r.e[1] = r.e[2] = -1;
     unsigned S1 = 0, S3 = 0;
-    for (int i = 0; i < 48; i++) {
+    for (int i = 0; i < nbits; i++) {
         if (bits[i] & 1u) {
-            int e = 47 - i;
+            int e = nbits - 1 - i;
             S1 ^= c_gf.exp[e];
             S3 ^= c_gf.exp[(3 * e) % 63];
         }
@@ -103,6 +103,21 @@ __device__ inline BchResult bch4836_decode(const uint8_t *bits)
         if (found == 3) { r.ok = 1; r.nflip = 3; }
     }
     return r;
+}
+
+__device__ inline BchResult bch4836_decode(const uint8_t *bits) { return bch_short_decode(bits, 48); }
+
+// systematic encode of k message bits: parity = m(x) x^12 mod g(x), g = x^12+x^10+x^8+x^5+x^4+x^3+1
+__device__ inline void bch_short_encode(const uint8_t *msg, int k, uint8_t *cw)
+{
+    unsigned rem = 0;
+    for (int j = 0; j < k; j++) {
+        unsigned fb = ((rem >> 11) & 1u) ^ (msg[j] & 1u);
+        rem = (rem << 1) & 0xfffu;
+        if (fb) rem ^= 0x539u;          // g(x) without the x^12 term: 0b0101_0011_1001
+        cw[j] = msg[j] & 1u;
+    }
+    for (int j = 0; j < 12; j++) cw[k + j] = (uint8_t)((rem >> (11 - j)) & 1u);
 }
 
 __device__ __forceinline__ unsigned getbits(const uint8_t *b, int n)
@@ -140,7 +155,7 @@ struct DecodeScratch {
 
 // Decode the burst held in s.sym; all 64 lanes of ONE wave must call this (blockDim.x == 64).
 __device__ inline void decode_burst_wave(DecodeScratch &s, uint32_t channel, uint64_t position,
-                                         amps_recc_burst_t *__restrict__ out)
+                                         amps_recc_burst_t *__restrict__ out, bool majority = false)
 {
     const int lane = threadIdx.x & 63;
     if (lane < 8) s.bad[lane] = 0;
@@ -164,37 +179,64 @@ __device__ inline void decode_burst_wave(DecodeScratch &s, uint32_t channel, uin
     }
     __syncthreads();
 
-    // ---- BCH: 7 words x 5 repeats, lib/recc_decode_impl.cc:100-107 ----
-    if (lane < 35) {
-        const int w = lane / 5, r = lane % 5;
-        BchResult br = bch4836_decode(&s.bits[7 + 240 * w + 48 * r]);
-        s.ok[lane] = (int8_t)br.ok;
-        s.flip[lane][0] = (int8_t)br.e[0];
-        s.flip[lane][1] = (int8_t)br.e[1];
-        s.flip[lane][2] = (int8_t)br.e[2];
-    }
-    __syncthreads();
-
     amps_recc_burst_t &o = s.rec;
-    if (lane < 7) {
-        const int w = lane;
-        int r = 0, ok = 0;
-        for (; r < 5; r++) if (s.ok[w * 5 + r]) { ok = 1; break; }
-        o.valid[w] = (uint8_t)ok;
-        o.first_valid_rep[w] = (uint8_t)r;
-        o.manch_bad[w] = (uint16_t)s.bad[1 + w];
-        const int rr = ok ? r : 4;
-        const uint8_t *src = &s.bits[7 + 240 * w + 48 * rr];
-        for (int i = 0; i < 36; i++) o.word_dec[w][i] = src[i];
-        if (ok) {
-            for (int f = 0; f < 3; f++) {
-                int e = s.flip[w * 5 + rr][f];
-                if (e >= 12 && e <= 47) o.word_dec[w][47 - e] ^= 1u;
+    if (!majority) {
+        // ---- BCH: 7 words x 5 repeats, lib/recc_decode_impl.cc:100-107 ----
+        if (lane < 35) {
+            const int w = lane / 5, r = lane % 5;
+            BchResult br = bch4836_decode(&s.bits[7 + 240 * w + 48 * r]);
+            s.ok[lane] = (int8_t)br.ok;
+            s.flip[lane][0] = (int8_t)br.e[0];
+            s.flip[lane][1] = (int8_t)br.e[1];
+            s.flip[lane][2] = (int8_t)br.e[2];
+        }
+        __syncthreads();
+        if (lane < 7) {
+            const int w = lane;
+            int r = 0, ok = 0;
+            for (; r < 5; r++) if (s.ok[w * 5 + r]) { ok = 1; break; }
+            o.valid[w] = (uint8_t)ok;
+            o.first_valid_rep[w] = (uint8_t)r;
+            o.manch_bad[w] = (uint16_t)s.bad[1 + w];
+            const int rr = ok ? r : 4;
+            const uint8_t *src = &s.bits[7 + 240 * w + 48 * rr];
+            for (int i = 0; i < 36; i++) o.word_dec[w][i] = src[i];
+            if (ok) {
+                for (int f = 0; f < 3; f++) {
+                    int e = s.flip[w * 5 + rr][f];
+                    if (e >= 12 && e <= 47) o.word_dec[w][47 - e] ^= 1u;
+                }
             }
         }
+        // raw repeat 0 of every word (what the reference parses)
+        for (int i = lane; i < 7 * 48; i += 64) o.word_raw[i / 48][i % 48] = s.bits[7 + 240 * (i / 48) + (i % 48)];
+    } else {
+        // ---- majority mode: bitwise 3-of-5 vote, one BCH decode per word, pad corrections rejected ----
+        for (int i = lane; i < 7 * 48; i += 64) {
+            const int w = i / 48, b = i % 48;
+            int cnt = 0;
+            for (int r = 0; r < 5; r++) cnt += s.bits[7 + 240 * w + 48 * r + b];
+            o.word_raw[w][b] = (uint8_t)(cnt >= 3);
+        }
+        __syncthreads();
+        if (lane < 7) {
+            const int w = lane;
+            BchResult br = bch4836_decode(o.word_raw[w]);
+            int ok = br.ok;
+            for (int f = 0; f < 3; f++) if (br.e[f] >= 48) ok = 0;          // a "correction" in the 15 shortening zeros
+            o.valid[w] = (uint8_t)ok;
+            int agree = 0;
+            for (int r = 0; r < 5; r++) {
+                int same = 1;
+                for (int b = 0; b < 48; b++) if (s.bits[7 + 240 * w + 48 * r + b] != o.word_raw[w][b]) { same = 0; break; }
+                agree += same;
+            }
+            o.first_valid_rep[w] = (uint8_t)agree;
+            o.manch_bad[w] = (uint16_t)s.bad[1 + w];
+            for (int i = 0; i < 36; i++) o.word_dec[w][i] = o.word_raw[w][i];
+            if (ok) for (int f = 0; f < 3; f++) { int e = br.e[f]; if (e >= 12 && e <= 47) o.word_dec[w][47 - e] ^= 1u; }
+        }
     }
-    // raw repeat 0 of every word (what the reference parses) + dcc
-    for (int i = lane; i < 7 * 48; i += 64) o.word_raw[i / 48][i % 48] = s.bits[7 + 240 * (i / 48) + (i % 48)];
     if (lane < 7) o.dcc[lane] = s.bits[lane];
     __syncthreads();
 
@@ -204,7 +246,18 @@ __device__ inline void decode_burst_wave(DecodeScratch &s, uint32_t channel, uin
         o.position = position;
         o.flags = s.nonbin ? AMPS_BURST_FLAG_NONBINARY : 0u;
         o.dcc_bad = (uint8_t)s.bad[0];
-        const uint8_t *A = o.word_raw[0], *B = o.word_raw[1];
+        // reference mode parses the raw repeat 0 (lib/recc_decode_impl.cc:112,117); majority mode the corrected word.
+        // word_dec holds 36 bits = everything the field parsers read (the last 12 of the 48 are parity).
+        bool used_ok = true;             // majority mode: every word the dispatch reads must have decoded
+        auto W = [&](int w) -> const uint8_t * { used_ok = used_ok && o.valid[w]; return majority ? o.word_dec[w] : o.word_raw[w]; };
+        const uint8_t *A = W(0), *B = W(1);
+        if (majority) {   // coded DCC: 0000000 / 0011111 / 1100011 / 1111100, accept within one bit
+            const unsigned codes[4] = { 0x00, 0x1f, 0x63, 0x7c };
+            unsigned d = getbits(o.dcc, 7);
+            bool good = false;
+            for (int i = 0; i < 4; i++) if (__popc(d ^ codes[i]) <= 1) good = true;
+            if (!good) o.flags |= AMPS_BURST_FLAG_DCC_INVALID;
+        }
         o.a_F = A[0] & 1u; o.a_NAWC = (uint8_t)getbits(A + 1, 3);
         o.a_T = A[4] & 1u; o.a_S = A[5] & 1u; o.a_E = A[6] & 1u; o.a_ER = A[7] & 1u;
         o.a_SCM = (uint8_t)getbits(A + 8, 4); o.a_MIN1 = getbits(A + 12, 24);
@@ -229,7 +282,7 @@ __device__ inline void decode_burst_wave(DecodeScratch &s, uint32_t channel, uin
             o.msg_class = AMPS_MSG_REGISTRATION;
             o.has_esn = o.a_S;
             if (o.a_S && o.a_NAWC > 1) {
-                const uint8_t *Cw = o.word_raw[2];
+                const uint8_t *Cw = W(2);
                 o.esn = getbits(Cw + 4, 32);
                 uint8_t nawc = (uint8_t)(o.a_NAWC - 2);
                 if ((uint8_t)getbits(Cw + 1, 3) != nawc) o.flags |= AMPS_BURST_FLAG_WORDC_NAWC_MISMATCH;
@@ -239,7 +292,7 @@ __device__ inline void decode_burst_wave(DecodeScratch &s, uint32_t channel, uin
             unsigned next = 2;
             o.has_esn = o.a_S;
             if (o.a_S) {
-                const uint8_t *Cw = o.word_raw[next++];
+                const uint8_t *Cw = W(next++);
                 o.esn = getbits(Cw + 4, 32);
                 nawc = (uint8_t)(o.a_NAWC - 2);
                 if ((uint8_t)getbits(Cw + 1, 3) != nawc) o.flags |= AMPS_BURST_FLAG_WORDC_NAWC_MISMATCH;
@@ -249,7 +302,7 @@ __device__ inline void decode_burst_wave(DecodeScratch &s, uint32_t channel, uin
                 o.msg_class = AMPS_MSG_ORIGINATION;
                 int dl = 0;
                 for (; nawc > 0; nawc--) {
-                    unsigned digs = getbits(o.word_raw[next++] + 4, 32);
+                    unsigned digs = getbits(W(next++) + 4, 32);
                     for (int i = 0; i < 8; i++) {       // recc_word_called::digits(), amps_packet.h:211-273
                         unsigned v = (digs >> 28) & 0xf;
                         if (v == 0) break;
@@ -261,6 +314,7 @@ __device__ inline void decode_burst_wave(DecodeScratch &s, uint32_t channel, uin
                 }
             }
         } else o.msg_class = AMPS_MSG_UNKNOWN;
+        if (majority && !used_ok && o.msg_class >= AMPS_MSG_PAGE_RESPONSE) o.msg_class = AMPS_MSG_INVALID_WORD_A;
     }
     __syncthreads();
     // coalesced copy of the staged record to HBM

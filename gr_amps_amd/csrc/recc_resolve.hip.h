@@ -95,6 +95,7 @@ struct CaptureArgs {
     uint32_t *nrecords;       // atomic
     uint32_t rec_cap;
     uint32_t *status;         // bit 2: record list overflow
+    uint32_t majority;        // decode mode (AMPS_RECC_FLAG_MAJORITY)
 };
 
 __global__ __launch_bounds__(64) void recc_capture_kernel(CaptureArgs a)
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(64) void recc_capture_kernel(CaptureArgs a)
         if (lane == 0) s_slot = atomicAdd(a.nrecords, 1u);
         __syncthreads();
         const uint32_t slot = s_slot;
-        if (slot < a.rec_cap) decode_burst_wave(s, c, nc, a.records + slot);
+        if (slot < a.rec_cap) decode_burst_wave(s, c, nc, a.records + slot, a.majority != 0);
         else { if (lane == 0) atomicOr(a.status, 4u); }
         __syncthreads();
     }
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(64) void recc_capture_kernel(CaptureArgs a)
 
 // recc_decode core on a batch of 3374-byte bursts (amps_recc_decode_bursts)
 __global__ __launch_bounds__(64) void recc_decode_bursts_kernel(const uint8_t *bursts, const uint32_t *chan,
-                                                                uint32_t nbursts, amps_recc_burst_t *out)
+                                                                uint32_t nbursts, amps_recc_burst_t *out, uint32_t majority)
 {
     __shared__ DecodeScratch s;
     const int lane = threadIdx.x;
@@ -133,8 +134,37 @@ __global__ __launch_bounds__(64) void recc_decode_bursts_kernel(const uint8_t *b
         const uint8_t *b = bursts + (uint64_t)q * AMPS_RECC_CAPTURE_SYMS;
         for (int i = lane; i < AMPS_RECC_CAPTURE_SYMS; i += 64) s.sym[i] = b[i];
         __syncthreads();
-        decode_burst_wave(s, chan ? chan[q] : 0u, 0ull, out + q);
+        decode_burst_wave(s, chan ? chan[q] : 0u, 0ull, out + q, majority != 0);
         __syncthreads();
+    }
+}
+
+// BCH(63,51) shortened to (k+12, k): one code word per lane (amps_bch_encode_words / amps_bch_decode_words)
+__global__ __launch_bounds__(256) void bch_encode_words_kernel(const uint8_t *msg, uint32_t n, int k, uint8_t *cw)
+{
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        uint8_t m[51], c[63];
+        for (int j = 0; j < k; j++) m[j] = msg[(uint64_t)i * k + j];
+        bch_short_encode(m, k, c);
+        for (int j = 0; j < k + 12; j++) cw[(uint64_t)i * (k + 12) + j] = c[j];
+    }
+}
+__global__ __launch_bounds__(256) void bch_decode_words_kernel(const uint8_t *cw, uint32_t n, int k, uint8_t *msg, uint8_t *valid,
+                                                               uint8_t *nerr)
+{
+    const int nb = k + 12;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        uint8_t c[63];
+        for (int j = 0; j < nb; j++) c[j] = cw[(uint64_t)i * nb + j] & 1u;
+        BchResult r = bch_short_decode(c, nb);
+        int ok = r.ok;
+        for (int f = 0; f < 3; f++) {
+            if (r.e[f] >= nb) ok = 0;                      // a "correction" inside the shortening zeros
+            else if (r.ok && r.e[f] >= 0) c[nb - 1 - r.e[f]] ^= 1u;
+        }
+        for (int j = 0; j < k; j++) msg[(uint64_t)i * k + j] = ok ? c[j] : (cw[(uint64_t)i * nb + j] & 1u);
+        valid[i] = (uint8_t)ok;
+        nerr[i] = (uint8_t)(ok ? r.nflip : 0xff);
     }
 }
 

@@ -56,6 +56,7 @@ extern "C" {
 
 /* amps_recc_cfg_t.flags */
 #define AMPS_RECC_FLAG_TIME_KERNELS 0x1u /* record HIP events around every kernel (amps_recc_get_timing) */
+#define AMPS_RECC_FLAG_MAJORITY     0x2u /* decode mode "majority" instead of "reference" (SURVEY.md 8f.2), see below */
 
 /* message classes, the branches of lib/recc_decode_impl.cc:108-168 */
 enum amps_recc_msg_class {
@@ -68,10 +69,21 @@ enum amps_recc_msg_class {
     AMPS_MSG_UNKNOWN        = 6  /* "got unknown RECC message"         (:166-168) */
 };
 
+/* Decode modes.
+ * reference (default): exactly lib/recc_decode_impl.cc:96-117 -- the five repeats are BCH-decoded in order and
+ *   the first that decodes wins; only validwords[0] gates; fields are parsed from the RAW repeat 0.
+ * majority (AMPS_RECC_FLAG_MAJORITY): what TIA/EIA-553 specifies and the reference leaves as "XXX" -- each of
+ *   the 48 bit positions of a word is a 3-of-5 vote over the repeats; the voted word is BCH-decoded once and is
+ *   valid only if it decodes AND no correction falls into the 15 shortening positions; fields are parsed from the
+ *   corrected bits; every word the dispatch reads must be valid; the 7-bit coded DCC must be within one bit of a
+ *   code word.  In this mode word_raw = voted bits, first_valid_rep = number of repeats equal to the voted word.
+ *   On error-free bursts both modes produce the same words, fields and class. */
+
 /* amps_recc_burst_t.flags */
 #define AMPS_BURST_FLAG_NONBINARY 0x1u /* a symbol byte outside {0,1} was seen (reference: assert(0), UB in Release) */
 #define AMPS_BURST_FLAG_WORDC_NAWC_MISMATCH 0x2u /* "protocol violation" warning of :134-136 / :150-152 */
 #define AMPS_BURST_FLAG_BAD_DIGIT 0x4u /* digit code 13..15 truncated a called-address word (amps_packet.h:219-223) */
+#define AMPS_BURST_FLAG_DCC_INVALID 0x8u /* majority mode: coded DCC further than one bit from every code word */
 
 /* One decoded seizure burst.  Bits are one byte per bit (0/1), MSB first, exactly as the reference
  * holds them (lib/recc_decode_impl.cc:92-95).  Layout is fixed: natural alignment, 728 bytes. */
@@ -196,6 +208,15 @@ typedef struct amps_recc_reply {
     uint8_t  has_command; char command[48];
 } amps_recc_reply_t;
 int amps_recc_reply_words(const amps_recc_burst_t *burst, amps_recc_reply_t *reply);
+
+/* BCH(63,51,t=2) shortened to (k+12,k) on the device, one code word per lane: k = 36 -> RECC (48,36),
+ * k = 28 -> FOCC/FVC (40,28) as encoded by focc_impl::focc_bch / fvc_impl::fvc_bch (lib/focc_impl.cc:156-176,
+ * lib/fvc_impl.cc:98-107).  Bits are one byte each, MSB first; arrays are [nwords][k] / [nwords][k+12], host or
+ * device per `mem`; results are host arrays.  valid[i] = 1 iff the word decodes with no correction inside the
+ * 63-(k+12) shortening positions. */
+int amps_bch_encode_words(amps_recc_t *h, const uint8_t *msg, size_t nwords, int k, int mem, uint8_t *codewords);
+int amps_bch_decode_words(amps_recc_t *h, const uint8_t *codewords, size_t nwords, int k, int mem,
+                          uint8_t *msg, uint8_t *valid, uint8_t *nerrors);
 
 #ifdef __cplusplus
 }

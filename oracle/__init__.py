@@ -84,6 +84,7 @@ def lib():
     L.orc_recc_bch_decode.restype = C.c_int
     L.orc_bch_encode_short.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.orc_decode_burst.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
+    L.orc_decode_burst_mode.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_int]
     L.orc_reply_words.argtypes = [C.c_void_p, C.POINTER(Reply)]
     L.orc_parse_min.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.orc_parse_min.restype = C.c_int
@@ -233,13 +234,13 @@ def recc_bch_decode(bits48):
     return bool(ok), dst
 
 
-def decode_bursts(bursts, channels=None, positions=None):
+def decode_bursts(bursts, channels=None, positions=None, majority=False):
     bursts = _u8(bursts).reshape(-1, CAPTURE)
     out = np.zeros(bursts.shape[0], BURST_DTYPE)
     for i in range(bursts.shape[0]):
         ch = 0 if channels is None else int(channels[i])
         pos = 0 if positions is None else int(positions[i])
-        lib().orc_decode_burst(_ptr(bursts[i]), ch, pos, C.c_void_p(out.ctypes.data + i * BURST_DTYPE.itemsize))
+        lib().orc_decode_burst_mode(_ptr(bursts[i]), ch, pos, C.c_void_p(out.ctypes.data + i * BURST_DTYPE.itemsize), int(majority))
     return out
 
 

@@ -52,6 +52,9 @@ void orc_bch_encode_short(const uint8_t *msg, int k, uint8_t *cw);     /* (k+12,
 /* ---------------- R5-R8: bursts_message (lib/recc_decode_impl.cc:81-169) ---------------- */
 void orc_decode_burst(const uint8_t burst[AMPS_RECC_CAPTURE_SYMS], uint32_t channel, uint64_t position,
                       amps_recc_burst_t *out);
+/* majority != 0: CPU model of the product's optional majority decode mode (not reference behaviour) */
+void orc_decode_burst_mode(const uint8_t burst[AMPS_RECC_CAPTURE_SYMS], uint32_t channel, uint64_t position,
+                           amps_recc_burst_t *out, int majority);
 void orc_reply_words(const amps_recc_burst_t *burst, amps_recc_reply_t *reply); /* :181-272 */
 
 /* R6/R7 helpers (lib/amps_packet.h, lib/amps_packet.cc) */

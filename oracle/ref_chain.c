@@ -376,9 +376,12 @@ void orc_focc_word2_voice_channel(uint8_t w[28], unsigned scc, uint64_t min2, un
 
 /* ===================================================================================== R5 / R8 */
 
-/* lib/recc_decode_impl.cc:81-169 */
-void orc_decode_burst(const uint8_t burst[AMPS_RECC_CAPTURE_SYMS], uint32_t channel, uint64_t position,
-                      amps_recc_burst_t *o)
+/* lib/recc_decode_impl.cc:81-169 when majority == 0.  majority != 0 is NOT reference behaviour: it is the CPU
+ * model of the product's optional "majority" decode mode (include/amps_recc.h "Decode modes"):
+ * bitwise 3-of-5 vote per word, one BCH decode, corrections inside the 15 shortening zeros rejected, fields from
+ * the corrected bits, every word the dispatch reads must be valid, coded DCC within one bit of a code word. */
+void orc_decode_burst_mode(const uint8_t burst[AMPS_RECC_CAPTURE_SYMS], uint32_t channel, uint64_t position,
+                           amps_recc_burst_t *o, int majority)
 {
     uint8_t words[AMPS_RECC_WORDS][240];
     int nonbin = 0;
@@ -388,22 +391,49 @@ void orc_decode_burst(const uint8_t burst[AMPS_RECC_CAPTURE_SYMS], uint32_t chan
     o->dcc_bad = (uint8_t)orc_manchester_decode_binbuf(burst, o->dcc, 7, &nonbin);          /* :90 */
     for (int i = 0; i < AMPS_RECC_WORDS; i++)                                                   /* :96-99 */
         o->manch_bad[i] = (uint16_t)orc_manchester_decode_binbuf(burst + 14 + 480 * i, words[i], 240, &nonbin);
-    for (int w = 0; w < AMPS_RECC_WORDS; w++) {                                                 /* :100-107 */
-        uint8_t dec[36];
-        int r, ok = 0;
-        for (r = 0; r < AMPS_RECC_REPEATS; r++) {
-            ok = orc_recc_bch_decode(&words[w][r * 48], dec);
-            if (ok) break;
+    for (int w = 0; w < AMPS_RECC_WORDS; w++) {
+        if (!majority) {                                                                        /* :100-107 */
+            uint8_t dec[36];
+            int r, ok = 0;
+            for (r = 0; r < AMPS_RECC_REPEATS; r++) {
+                ok = orc_recc_bch_decode(&words[w][r * 48], dec);
+                if (ok) break;
+            }
+            o->valid[w] = (uint8_t)ok;
+            o->first_valid_rep[w] = (uint8_t)r; /* 5 when none decoded */
+            memcpy(o->word_dec[w], dec, 36);    /* last attempt: the valid one, or uncorrected repeat 4 */
+            memcpy(o->word_raw[w], words[w], 48);
+        } else {
+            uint8_t padded[63], corr[63];
+            int nflip = 0, agree = 0;
+            for (int b = 0; b < 48; b++) {
+                int cnt = 0;
+                for (int r = 0; r < AMPS_RECC_REPEATS; r++) cnt += words[w][r * 48 + b];
+                o->word_raw[w][b] = (uint8_t)(cnt >= 3);
+            }
+            memset(padded, 0, 15);
+            memcpy(padded + 15, o->word_raw[w], 48);
+            int ok = orc_bch63_decode(padded, corr, &nflip);
+            for (int b = 0; b < 15; b++) if (corr[b]) ok = 0;   /* "correction" inside the shortening zeros */
+            o->valid[w] = (uint8_t)ok;
+            for (int r = 0; r < AMPS_RECC_REPEATS; r++) agree += memcmp(&words[w][r * 48], o->word_raw[w], 48) == 0;
+            o->first_valid_rep[w] = (uint8_t)agree;
+            memcpy(o->word_dec[w], ok ? corr + 15 : o->word_raw[w], 36);
         }
-        o->valid[w] = (uint8_t)ok;
-        o->first_valid_rep[w] = (uint8_t)r; /* 5 when none decoded */
-        memcpy(o->word_dec[w], dec, 36);    /* last attempt: the valid one, or uncorrected repeat 4 */
-        memcpy(o->word_raw[w], words[w], 48);
     }
     if (nonbin) o->flags |= AMPS_BURST_FLAG_NONBINARY;
+    if (majority) {
+        static const unsigned codes[4] = { 0x00, 0x1f, 0x63, 0x7c };
+        unsigned d = getbits(o->dcc, 7);
+        int good = 0;
+        for (int i = 0; i < 4; i++) if (__builtin_popcount(d ^ codes[i]) <= 1) good = 1;
+        if (!good) o->flags |= AMPS_BURST_FLAG_DCC_INVALID;
+    }
 
-    /* fields are always parsed from the raw repeat 0 (:112, :117), also for dropped bursts (kept for inspection) */
-    const uint8_t *A = o->word_raw[0], *B = o->word_raw[1];
+    /* reference: fields are always parsed from the raw repeat 0 (:112, :117), also for dropped bursts */
+    int used_ok = 1;
+#define WORD(w) (used_ok = used_ok && o->valid[(w)], majority ? o->word_dec[(w)] : o->word_raw[(w)])
+    const uint8_t *A = WORD(0), *B = WORD(1);
     o->a_F = A[0] & 1u; o->a_NAWC = (uint8_t)getbits(A + 1, 3);                                 /* amps_packet.h:108-113 */
     o->a_T = A[4] & 1u; o->a_S = A[5] & 1u; o->a_E = A[6] & 1u; o->a_ER = A[7] & 1u;            /* :154-161 */
     o->a_SCM = (uint8_t)getbits(A + 8, 4); o->a_MIN1 = getbits(A + 12, 24);
@@ -414,16 +444,16 @@ void orc_decode_burst(const uint8_t burst[AMPS_RECC_CAPTURE_SYMS], uint32_t chan
     o->b_SDCC2 = (uint8_t)getbits(B + 24, 2); o->b_MIN2 = (uint16_t)getbits(B + 26, 10);
     orc_calc_min(o->a_MIN1, o->b_MIN2, o->min);
 
-    if (!o->valid[0]) { o->msg_class = AMPS_MSG_INVALID_WORD_A; return; }                       /* :108-111 */
-    if (!o->a_E) { o->msg_class = AMPS_MSG_E_ZERO; return; }                                    /* :113-116 */
     int zero_order = (o->b_ORDER == 0 && o->b_ORDQ == 0 && o->b_MSG_TYPE == 0);
-    if (o->a_T == 0 && zero_order) {                                                            /* :121-122 */
+    if (!o->valid[0]) o->msg_class = AMPS_MSG_INVALID_WORD_A;                                   /* :108-111 */
+    else if (!o->a_E) o->msg_class = AMPS_MSG_E_ZERO;                                           /* :113-116 */
+    else if (o->a_T == 0 && zero_order) {                                                       /* :121-122 */
         o->msg_class = AMPS_MSG_PAGE_RESPONSE;
     } else if (o->a_T == 1 && o->b_ORDER == 0xd) {                                              /* :123-138 */
         o->msg_class = AMPS_MSG_REGISTRATION;
         o->has_esn = o->a_S;
         if (o->a_S && o->a_NAWC > 1) {
-            const uint8_t *C = o->word_raw[2];
+            const uint8_t *C = WORD(2);
             o->esn = getbits(C + 4, 32);
             uint8_t nawc = (uint8_t)(o->a_NAWC - 2);
             if ((uint8_t)getbits(C + 1, 3) != nawc) o->flags |= AMPS_BURST_FLAG_WORDC_NAWC_MISMATCH;
@@ -433,25 +463,36 @@ void orc_decode_burst(const uint8_t burst[AMPS_RECC_CAPTURE_SYMS], uint32_t chan
         unsigned next = 2;
         o->has_esn = o->a_S;
         if (o->a_S) {
-            const uint8_t *C = o->word_raw[next++];
+            const uint8_t *C = WORD(next); next++;
             o->esn = getbits(C + 4, 32);
             nawc = (uint8_t)(o->a_NAWC - 2); /* unsigned char arithmetic: wraps for NAWC < 2 */
             if ((uint8_t)getbits(C + 1, 3) != nawc) o->flags |= AMPS_BURST_FLAG_WORDC_NAWC_MISMATCH;
         }
-        if (nawc < 1 || nawc > 4) { o->msg_class = AMPS_MSG_BAD_NAWC; return; }                 /* :155-158 */
-        o->msg_class = AMPS_MSG_ORIGINATION;
-        size_t dl = 0;
-        for (; nawc > 0; nawc--) {
-            char d[9]; int bad = 0;
-            orc_called_digits(getbits(o->word_raw[next++] + 4, 32), d, &bad);
-            if (bad) o->flags |= AMPS_BURST_FLAG_BAD_DIGIT;
-            size_t l = strlen(d);
-            memcpy(o->dialed + dl, d, l); dl += l;
-            o->n_called_words++;
+        if (nawc < 1 || nawc > 4) o->msg_class = AMPS_MSG_BAD_NAWC;                             /* :155-158 */
+        else {
+            o->msg_class = AMPS_MSG_ORIGINATION;
+            size_t dl = 0;
+            for (; nawc > 0; nawc--) {
+                char d[9]; int bad = 0;
+                const uint8_t *Dw = WORD(next); next++;
+                orc_called_digits(getbits(Dw + 4, 32), d, &bad);
+                if (bad) o->flags |= AMPS_BURST_FLAG_BAD_DIGIT;
+                size_t l = strlen(d);
+                memcpy(o->dialed + dl, d, l); dl += l;
+                o->n_called_words++;
+            }
         }
     } else {
         o->msg_class = AMPS_MSG_UNKNOWN;                                                        /* :166-168 */
     }
+#undef WORD
+    if (majority && !used_ok && o->msg_class >= AMPS_MSG_PAGE_RESPONSE) o->msg_class = AMPS_MSG_INVALID_WORD_A;
+}
+
+void orc_decode_burst(const uint8_t burst[AMPS_RECC_CAPTURE_SYMS], uint32_t channel, uint64_t position,
+                      amps_recc_burst_t *o)
+{
+    orc_decode_burst_mode(burst, channel, position, o, 0);
 }
 
 /* lib/recc_decode_impl.cc:181-272; GLOBAL_DCC_SHORT = 0, GLOBAL_SCC = 1 (amps_packet.h:13-14), STREAM_BOTH = 3 (:33) */

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     hdr = open(os.path.join(ROOT, "include", "amps_recc.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(amps_recc_[a-z_]+)\s*\(", hdr)))
+    return sorted(set(re.findall(r"\b(amps_(?:recc|bch)_[a-z_]+)\s*\(", hdr)))
 
 
 def test_library_exports_every_declared_symbol():

@@ -287,3 +287,62 @@ def test_full_size_roundtrip_properties(gpu):
     for rec in got:
         assert rec["min"].decode() in mins[int(rec["channel"]) % base]
         assert rec["valid"].all()
+
+
+# ------------------------------------------------------------------ SURVEY.md 8f.2 / 8f.3
+def test_majority_mode_matches_its_cpu_model_and_the_reference_on_clean_bursts(gpu):
+    rng = np.random.default_rng(41)
+    clean, noisy = [], []
+    for i in range(24):
+        _, _, _, _, words = synth.random_message(rng)
+        syms = synth.manchester(synth.burst_bits(words, dcc=int(rng.integers(0, 4)), rng=rng))[82:82 + CAPTURE]
+        clean.append(syms)
+        noisy.append(_corrupt(syms, rng, int(rng.integers(40, 400))))
+    clean, noisy = np.stack(clean), np.stack(noisy)
+    with capi.Recc(n_channels=1, max_bursts=4, majority=True) as r:
+        got_c, got_n = r.decode_bursts(clean), r.decode_bursts(noisy)
+    with capi.Recc(n_channels=1, max_bursts=4) as r:
+        ref_c, ref_n = r.decode_bursts(clean), r.decode_bursts(noisy)
+    assert got_c.tobytes() == oracle.decode_bursts(clean, majority=True).tobytes()
+    assert got_n.tobytes() == oracle.decode_bursts(noisy, majority=True).tobytes()
+    # clean bursts: same words, fields and class as the reference mode
+    for f in ("word_dec", "valid", "msg_class", "min", "dialed", "esn", "a_MIN1", "b_MIN2", "dcc"):
+        assert np.array_equal(got_c[f], ref_c[f]), f
+    assert (got_c["first_valid_rep"] == 5).all() and (got_c["flags"] == 0).all()
+    # heavy symbol errors: the 3-of-5 vote recovers at least as many bursts as first-valid-of-five
+    ok_major = (got_n["msg_class"] >= 2).sum()
+    ok_ref = sum(int(a["msg_class"] >= 2 and a["min"] == c["min"]) for a, c in zip(ref_n, ref_c))
+    right_major = sum(int(a["msg_class"] >= 2 and a["min"] == c["min"]) for a, c in zip(got_n, ref_c))
+    assert right_major >= ok_ref and right_major == ok_major      # and never a wrong MIN
+
+
+def test_bch_40_28_and_48_36_words_on_the_device(gpu):
+    rng = np.random.default_rng(43)
+    with capi.Recc(n_channels=1, max_bursts=4) as r:
+        for k in (28, 36):
+            msg = rng.integers(0, 2, (500, k)).astype(np.uint8)
+            cw = r.bch_encode(msg)
+            assert cw.shape == (500, k + 12)
+            for i in range(0, 500, 50):                                    # encoder == oracle / synth encoder
+                assert list(cw[i]) == list(oracle.bch_encode(msg[i])) == synth.bch_encode(msg[i])
+            rx = cw.copy()
+            nerr = rng.integers(0, 4, 500)
+            for i in range(500):
+                rx[i, rng.choice(k + 12, nerr[i], replace=False)] ^= 1
+            dec, valid, ne = r.bch_decode(rx)
+            le2 = nerr <= 2
+            assert valid[le2].all() and np.array_equal(dec[le2], msg[le2]) and np.array_equal(ne[le2], nerr[le2])
+            # 3 errors: either rejected or miscorrected -- identical to the IT++ restatement with pad rejection
+            for i in np.nonzero(~le2)[0][:60]:
+                padded = np.concatenate([np.zeros(63 - (k + 12), np.uint8), rx[i]])
+                ok, out, nf = oracle.bch63_decode(padded)
+                ok = ok and not out[:63 - (k + 12)].any()
+                assert bool(valid[i]) == bool(ok)
+                if ok:
+                    assert np.array_equal(dec[i], out[63 - (k + 12):63 - 12])
+        # the FOCC control-filler word of the reference (lib/focc_impl.cc:294) round-trips through (40,28)
+        filler = np.array([[int(c) for c in "1100010111000001100111111001"]], np.uint8)
+        cw = r.bch_encode(filler)
+        assert "".join(map(str, cw[0, 28:])) == "001000000011"
+        d, v, _ = r.bch_decode(cw)
+        assert v[0] == 1 and np.array_equal(d, filler)
