@@ -200,9 +200,10 @@ def run_workload(name, a, torch, dev, dist, rank, world, local):
     if wide:   # dominant kernel = the channelizer; algorithmic bytes = the wideband block read once (14.77 B/symbol)
         kms = tm["ms_channelizer"] / max(1, tm["launches_channelizer"])
         alg_bytes = 8.0 * NW
-        kname = "chz_pfb_fft_kernel<8>"
-        note = ("filter bank + FFT = ~28 flop per input byte: VALU-issue bound, not HBM bound; the HBM fraction is what the "
-                "metric asks for.  recc_front_kernel then streams the channel-major intermediate (see other_kernels)")
+        kname = "chz_fused_kernel<8>"
+        note = ("filter bank + FFT-1024 + FM discriminator + boxcar + slicer in one kernel (~35 flop per input byte): latency/VALU "
+                "bound, not HBM bound; the HBM fraction is what the metric asks for.  Only slicer bits (1/64 of the input) reach HBM; "
+                "the bit-domain correlator (ms_front) and the decode kernels follow")
     else:
         kms = tm["ms_front"] / max(1, tm["launches_front"])
         alg_bytes = ALG_BYTES_PER_SYMBOL_DIRECT * syms_per_step_rank

@@ -17,6 +17,7 @@ MAX_WORK_ITEMS = 61439
 MEM_HOST, MEM_DEVICE = 0, 1
 FLAG_TIME_KERNELS = 1
 FLAG_MAJORITY = 2
+FLAG_UNFUSED_WIDEBAND = 4
 
 MSG_CLASSES = ("invalid_word_a", "e_zero", "page_response", "registration", "origination", "bad_nawc", "unknown")
 
@@ -142,7 +143,7 @@ class Recc:
     """One handle = `n_channels` independent RECC receivers on one MI355X."""
 
     def __init__(self, n_channels=1, sps=10, max_samples=0, max_bursts=1024, device=-1, time_kernels=False,
-                 stream=None, wideband=None, majority=False):
+                 stream=None, wideband=None, majority=False, unfused_wideband=False):
         L = load()
         cfg = Cfg()
         cfg.struct_size = C.sizeof(Cfg)
@@ -151,7 +152,8 @@ class Recc:
         cfg.max_samples_per_push = max_samples
         cfg.max_bursts = max_bursts
         cfg.device = device
-        cfg.flags = (FLAG_TIME_KERNELS if time_kernels else 0) | (FLAG_MAJORITY if majority else 0)
+        cfg.flags = ((FLAG_TIME_KERNELS if time_kernels else 0) | (FLAG_MAJORITY if majority else 0)
+                     | (FLAG_UNFUSED_WIDEBAND if unfused_wideband else 0))
         cfg.stream = stream
         if wideband:
             cfg.wideband_channels = wideband["channels"]

@@ -548,6 +548,51 @@ int amps_recc_push_iq(amps_recc_t *h, const float *iq, size_t ld, size_t nsamp, 
     return run_iq_device(h, d, dld, (uint32_t)nsamp);
 }
 
+namespace {
+// bit-domain tail of the fused wideband seam: the slicer bits of [n_done, n_done + P) are already in the ring
+int run_bits_device(amps_recc *h, uint32_t P)
+{
+    if (P == 0) return 0;
+    hipStream_t s = h->stream;
+    const uint32_t Tc = (P + TILE - 1) / TILE;
+    const uint64_t G = (uint64_t)h->C * Tc;
+    uint32_t nwaves = (uint32_t)std::min<uint64_t>(h->max_waves, (G + MIN_SPAN - 1) / MIN_SPAN);
+    if (nwaves == 0) nwaves = 1;
+    const uint32_t span = (uint32_t)((G + nwaves - 1) / nwaves);
+    if ((uint64_t)(Tc + span - 1) / span + 1 > h->max_chunks) return -E2BIG;
+    FrontArgs fa{};
+    fa.r_prev = 0; fa.avail = P; fa.P = P; fa.tiles_per_channel = Tc; fa.n_channels = h->C; fa.span = span;
+    fa.n_done = h->n_done; fa.gring = h->gring; fa.ring_mask = h->ring_words - 1; fa.ring_words = h->ring_words;
+    fa.det = h->det; fa.detcount = h->detcount; fa.max_chunks = h->max_chunks; fa.det_cap = h->det_cap; fa.status = h->status;
+    {
+        SpanGuard g(h, T_FRONT, P);
+        hipLaunchKernelGGL((recc_front_kernel<3, 1, true>), dim3((nwaves + 3) / 4), dim3(256), 0, s, fa);
+    }
+    HIP_TRY(hipMemsetAsync(h->capq_count, 0, sizeof(uint32_t), s));
+    ResolveArgs ra{};
+    ra.det = h->det; ra.detcount = h->detcount; ra.max_chunks = h->max_chunks; ra.det_cap = h->det_cap;
+    ra.tiles_per_channel = Tc; ra.span = span; ra.sps = h->sps; ra.n_proc = h->n_done + P;
+    ra.next_allowed = h->next_allowed; ra.pending = h->pending; ra.capq = h->capq; ra.capq_count = h->capq_count;
+    ra.capq_cap = h->cfg.max_bursts; ra.status = h->status;
+    {
+        SpanGuard g(h, T_RESOLVE);
+        hipLaunchKernelGGL(recc_resolve_kernel, dim3(h->C), dim3(64), 0, s, ra);
+    }
+    CaptureArgs ca{};
+    ca.capq = h->capq; ca.capq_count = h->capq_count; ca.capq_cap = h->cfg.max_bursts; ca.sps = h->sps;
+    ca.gring = h->gring; ca.ring_mask = h->ring_words - 1; ca.ring_words = h->ring_words;
+    ca.records = h->records; ca.nrecords = h->nrecords; ca.rec_cap = h->cfg.max_bursts; ca.status = h->status;
+    ca.majority = (h->cfg.flags & AMPS_RECC_FLAG_MAJORITY) ? 1u : 0u;
+    {
+        SpanGuard g(h, T_DECODE);
+        hipLaunchKernelGGL(recc_capture_kernel, dim3(std::min<uint32_t>(h->cfg.max_bursts, 2048u)), dim3(64), 0, s, ca);
+    }
+    HIP_TRY(hipGetLastError());
+    h->n_done += P;
+    return 0;
+}
+} // namespace
+
 int amps_recc_push_wideband(amps_recc_t *h, const float *iq, size_t nsamp, int mem)
 {
     if (!h) return -EINVAL;
@@ -555,16 +600,20 @@ int amps_recc_push_wideband(amps_recc_t *h, const float *iq, size_t nsamp, int m
     if (nsamp == 0) return 0;
     if (!iq) return -EINVAL;
     HIP_TRY(hipSetDevice(h->device));
+    // Fused form (default): filter bank + discriminator + boxcar + slicer in one kernel, then the bit-domain
+    // correlator.  AMPS_RECC_FLAG_UNFUSED_WIDEBAND keeps the two-kernel form (channel-major intermediate in HBM).
+    const bool fused = !(h->cfg.flags & AMPS_RECC_FLAG_UNFUSED_WIDEBAND);
     const float2 *chan_iq = nullptr;
     uint64_t ld = 0;
     uint32_t nout = 0;
     int rc;
     {
         SpanGuard g(h, T_CHANNELIZER, nsamp);
-        rc = channelizer_run(h->chz, (const float2 *)iq, nsamp, mem, h->stream, &chan_iq, &ld, &nout);
+        rc = channelizer_run(h->chz, (const float2 *)iq, nsamp, mem, h->stream, &chan_iq, &ld, &nout, fused, h->gring, h->ring_words, h->n_done);
     }
     if (rc) return rc;
     if (nout > h->cfg.max_samples_per_push) return -E2BIG;
+    if (fused) return run_bits_device(h, nout);
     return run_iq_device(h, chan_iq, ld, nout);
 }
 

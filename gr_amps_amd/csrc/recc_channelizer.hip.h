@@ -53,7 +53,13 @@ struct ChzArgs {
     uint32_t first_bin;      // FFT bin of channel 0
     uint32_t n_channels;
     uint32_t odd_start;      // parity of (absolute frame index of frame 0 of this launch)
+    uint32_t hist;           // samples of history the carry holds before v = 0  (L - D + CHZ_PRE * D)
+    // fused form: slicer bits go straight to the RECC bit ring
+    uint64_t *gring;         // [C][ring_words]
+    uint32_t ring_words;
+    uint64_t n_done;         // absolute channel-stream sample index of frame 0 (multiple of 64)
 };
+constexpr int CHZ_PRE = 4;   // frames re-run in front of a workgroup's range to rebuild per-bin demod state (even)
 
 typedef float cf2 __attribute__((ext_vector_type(2)));
 
@@ -126,8 +132,8 @@ __global__ __launch_bounds__(256) void chz_pfb_fft_kernel(ChzArgs a)
     // virtual input stream of this launch: index v in [-(L-D), nsamp + leftover): carry then block.
     // frame f (launch-relative) consumes v in [f*D - (L-D), f*D + D); the absolute frame index of f = 0 is even
     // (the host only ever consumes an even number of frames), so parity(m) = parity(f) and residue(v) = v mod M.
-    const int64_t hist = (int64_t)L - D;
-    const int64_t lead = (int64_t)a.carry_len - hist;          // leftover samples (< 2D) that precede the block
+    const int64_t hist = (int64_t)a.hist;
+    const int64_t lead = (int64_t)a.carry_len - hist;          // leftover samples that precede the block
     auto fetch = [&](int64_t v) -> cf2 {
         int64_t ci = v + hist;                                  // index into carry
         if (ci < 0) return (cf2){ 0.f, 0.f };
@@ -202,6 +208,111 @@ __global__ __launch_bounds__(256) void chz_pfb_fft_kernel(ChzArgs a)
     }
 }
 
+// ---- fused form: channelizer + FM discriminator + boxcar + slicer; only 1 bit per channel sample reaches HBM ----
+// After the FFT a lane owns bins {t, t+256, t+512, t+768} in every frame, so the per-channel stream state of the
+// RECC front end is four small register sets: previous frame's value, the last two demod floats (boxcar over
+// 3 samples per symbol, ordered aligned-pair sums of include/amps_recc_numerics.h) and a 32-bit slicer shift
+// register that is stored to the channel's bit ring every 32 frames.  The arithmetic is the same as
+// recc_front_kernel's on the channel-major intermediate, so both forms produce identical bits.
+template <int PAR>
+__device__ __forceinline__ void chz_bins(const cf2 (&y)[4], cf2 (&prev)[4], float (&d1)[4], float (&d2)[4], uint32_t (&gw)[4])
+{
+    const f2 da = fm_phase_two(y[0], prev[0], y[1], prev[1]);
+    const f2 db = fm_phase_two(y[2], prev[2], y[3], prev[3]);
+    const float d[4] = { da.x, da.y, db.x, db.y };
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        // window [n-2, n]: n even -> (d[n-2] + d[n-1]) + d[n];  n odd -> d[n-2] + (d[n-1] + d[n])
+        const float s = PAR == 0 ? (d2[j] + d1[j]) + d[j] : d2[j] + (d1[j] + d[j]);
+        gw[j] = (gw[j] >> 1) | (s >= 0.0f ? 0x80000000u : 0u);
+        d2[j] = d1[j]; d1[j] = d[j]; prev[j] = y[j];
+    }
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void chz_fused_kernel(ChzArgs a)
+{
+    constexpr int M = CHZ_M, D = CHZ_D;
+    __shared__ cf2 bufA[CHZ_M];
+    __shared__ cf2 bufB[CHZ_M];
+    const int t = threadIdx.x;
+    const int64_t f0 = (int64_t)blockIdx.x * a.frames_per_wg;   // multiple of 64
+    if (f0 >= (int64_t)a.nframes) return;
+    int64_t f1 = f0 + a.frames_per_wg; if (f1 > (int64_t)a.nframes) f1 = a.nframes;
+    const int64_t fs = f0 - CHZ_PRE;                             // pre-roll: rebuild prev / d1 / d2 of every bin
+
+    const int64_t hist = (int64_t)a.hist;
+    const int64_t lead = (int64_t)a.carry_len - hist;
+    auto fetch = [&](int64_t v) -> cf2 {
+        int64_t ci = v + hist;
+        if (ci < 0) return (cf2){ 0.f, 0.f };
+        float2 s;
+        if (ci < (int64_t)a.carry_len) s = a.carry[ci];
+        else { int64_t bi = v - lead; if (bi >= (int64_t)a.nsamp) return (cf2){ 0.f, 0.f }; s = a.block[bi]; }
+        return (cf2){ s.x, s.y };
+    };
+    float coef[4][P];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int q = 0; q < P; q++) coef[j][q] = a.taps[t + 256 * j + q * M];
+    cf2 tw[4][3];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const int Ns = 4 << (2 * p);
+        const int k = t & (Ns - 1);
+        float sn, cs;
+        sincosf(-6.283185307179586f * (float)k / (float)(4 * Ns), &sn, &cs);
+        tw[p][0] = (cf2){ cs, sn };
+        tw[p][1] = cmul(tw[p][0], tw[p][0]);
+        tw[p][2] = cmul(tw[p][1], tw[p][0]);
+    }
+    cf2 line[4][P];
+    {
+        const int64_t vend = fs * D;                              // multiple of M (fs is even)
+#pragma unroll
+        for (int jb = 0; jb < 4; jb++) {
+            const int64_t vlast = vend - M + (t + 256 * jb);
+#pragma unroll
+            for (int q = 0; q < P; q++) line[jb][q] = fetch(vlast - (int64_t)M * (P - 1 - q));
+        }
+    }
+    cf2 prev[4] = {};
+    float d1[4] = {}, d2[4] = {};
+    uint32_t gw[4] = { ~0u, ~0u, ~0u, ~0u };
+    uint32_t ch[4];
+    uint32_t *ring32[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        ch[j] = ((uint32_t)(t + 256 * j) - a.first_bin) & (M - 1);
+        ring32[j] = (uint32_t *)(a.gring + (uint64_t)ch[j] * a.ring_words);
+    }
+    const uint64_t mask32 = 2ull * a.ring_words - 1;
+
+    cf2 nx0 = fetch(fs * D + t), nx1 = fetch(fs * D + 256 + t);
+    for (int64_t f = fs; f < f1; f += 2) {
+        cf2 y[4];
+        {
+            const cf2 c0 = nx0, c1 = nx1;
+            nx0 = fetch((f + 1) * D + t); nx1 = fetch((f + 1) * D + 256 + t);
+            chz_frame<P, 0>(line, coef, tw, c0, c1, bufA, bufB, t, y);
+            chz_bins<0>(y, prev, d1, d2, gw);
+        }
+        {
+            const cf2 c0 = nx0, c1 = nx1;
+            nx0 = fetch((f + 2) * D + t); nx1 = fetch((f + 2) * D + 256 + t);
+            chz_frame<P, 1>(line, coef, tw, c0, c1, bufA, bufB, t, y);
+            chz_bins<1>(y, prev, d1, d2, gw);
+        }
+        if (f >= f0 && ((f + 1) & 31) == 31) {                    // 32 real frames collected (f0 is a multiple of 64)
+            const uint64_t n = a.n_done + (uint64_t)(f + 1);      // absolute index of the newest bit
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (ch[j] < a.n_channels) ring32[j][(n >> 5) & mask32] = gw[j];
+        }
+    }
+}
+
 // carry_out[k] = virtual sample (consumed - hist + k), k in [0, hist + leftover_new)
 __global__ __launch_bounds__(256) void chz_carry_kernel(const float2 *block, const float2 *carry_in, float2 *carry_out,
                                                          uint32_t carry_len, uint32_t nsamp, uint32_t hist, uint32_t consumed,
@@ -265,14 +376,17 @@ inline std::vector<float> chz_design_taps(int P)
     return out;
 }
 
+inline uint32_t chz_hist(int P) { return (uint32_t)(P * CHZ_M - CHZ_D + CHZ_PRE * CHZ_D); }
+inline size_t chz_carry_cap(int P) { return (size_t)chz_hist(P) + 64 * CHZ_D; }   // + leftover (< 64 frames)
+
 inline int channelizer_reset(ChannelizerState &z, hipStream_t s)
 {
     if (!z.enabled) return 0;
-    const size_t cap = (size_t)z.P * CHZ_M + CHZ_D;   // hist + leftover (< 2D)
+    const size_t cap = chz_carry_cap(z.P);
     if (hipMemsetAsync(z.carry[0], 0, sizeof(float2) * cap, s) != hipSuccess) return -EIO;
     if (hipMemsetAsync(z.carry[1], 0, sizeof(float2) * cap, s) != hipSuccess) return -EIO;
     z.carry_cur = 0;
-    z.carry_len = (uint32_t)(z.P * CHZ_M - CHZ_D);   // all-zero history, no leftover
+    z.carry_len = chz_hist(z.P);                     // all-zero history, no leftover
     z.frames_done = 0;
     return 0;
 }
@@ -297,17 +411,21 @@ inline int channelizer_create(ChannelizerState &z, const amps_recc_cfg_t &cfg, h
     std::vector<float> h = chz_design_taps(P);
     if (hipMalloc((void **)&z.taps, sizeof(float) * L) != hipSuccess) return -ENOMEM;
     if (hipMemcpy(z.taps, h.data(), sizeof(float) * L, hipMemcpyHostToDevice) != hipSuccess) return -EIO;
-    if (hipMalloc((void **)&z.carry[0], sizeof(float2) * (L + CHZ_D)) != hipSuccess) return -ENOMEM;
-    if (hipMalloc((void **)&z.carry[1], sizeof(float2) * (L + CHZ_D)) != hipSuccess) return -ENOMEM;
+    if (hipMalloc((void **)&z.carry[0], sizeof(float2) * chz_carry_cap(P)) != hipSuccess) return -ENOMEM;
+    if (hipMalloc((void **)&z.carry[1], sizeof(float2) * chz_carry_cap(P)) != hipSuccess) return -ENOMEM;
     if (hipMalloc((void **)&z.out, sizeof(float2) * (size_t)z.C * z.ld) != hipSuccess) return -ENOMEM;
     z.enabled = true;
     (void)s;
     return 0;
 }
 
-// Channelise `nsamp` new wideband samples; on return *chan_iq / *ld / *nframes describe the channel-major block.
+// Channelise `nsamp` new wideband samples.
+//  fused = false: writes the channel-major block; *chan_iq / *ld / *nframes describe it (even number of frames).
+//  fused = true : runs discriminator + boxcar + slicer behind the FFT and writes only slicer bits into `gring`
+//                 at absolute sample index n_done.. ; consumes a multiple of 64 frames.
 inline int channelizer_run(ChannelizerState &z, const float2 *iq, size_t nsamp, int mem, hipStream_t s,
-                           const float2 **chan_iq, uint64_t *ld, uint32_t *nframes_out)
+                           const float2 **chan_iq, uint64_t *ld, uint32_t *nframes_out,
+                           bool fused = false, uint64_t *gring = nullptr, uint32_t ring_words = 0, uint64_t n_done = 0)
 {
     if (!z.enabled) return -ENOSYS;
     const float2 *d = iq;
@@ -321,33 +439,43 @@ inline int channelizer_run(ChannelizerState &z, const float2 *iq, size_t nsamp, 
         if (hipMemcpyAsync(z.stage, iq, sizeof(float2) * nsamp, hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
         d = z.stage;
     }
-    const uint32_t L = (uint32_t)z.P * CHZ_M, hist = L - CHZ_D;
+    const uint32_t hist = chz_hist(z.P);
     const uint32_t leftover = z.carry_len - hist;
     const uint64_t avail = (uint64_t)leftover + nsamp;
-    const uint32_t nframes = (uint32_t)(avail / CHZ_D) & ~1u;    // even: keeps the absolute frame parity of every launch at 0
+    // frames consumed: even (keeps the frame parity of a launch at 0), and in the fused form a multiple of 64
+    // (whole words of the RECC bit ring); the rest waits in the carry
+    const uint32_t nframes = (uint32_t)(avail / CHZ_D) & (fused ? ~63u : ~1u);
     if (nframes > z.max_frames) return -E2BIG;
     if (nframes) {
         ChzArgs a{};
         a.block = d; a.carry = z.carry[z.carry_cur]; a.taps = z.taps; a.out = z.out; a.ld = z.ld;
-        a.carry_len = z.carry_len; a.nsamp = (uint32_t)nsamp; a.nframes = nframes;
+        a.carry_len = z.carry_len; a.nsamp = (uint32_t)nsamp; a.nframes = nframes; a.hist = hist;
         uint32_t fpw = (nframes + 2047) / 2048;                       // aim for ~2048 workgroups
-        fpw = std::max<uint32_t>(64, fpw);                            // history refill = 2P-1 frames per workgroup
-        fpw = (fpw + CHZ_GROUP - 1) / CHZ_GROUP * CHZ_GROUP;
+        fpw = std::max<uint32_t>(fused ? 128 : 64, fpw);              // delay-line refill (+ pre-roll) per workgroup
+        fpw = (fpw + 63) / 64 * 64;
         a.frames_per_wg = fpw; a.first_bin = z.first_bin; a.n_channels = z.C;
         a.odd_start = 0;
+        a.gring = gring; a.ring_words = ring_words; a.n_done = n_done;
         const uint32_t nwg = (nframes + fpw - 1) / fpw;
-        if (z.P == 8) hipLaunchKernelGGL(chz_pfb_fft_kernel<8>, dim3(nwg), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(chz_pfb_fft_kernel<16>, dim3(nwg), dim3(256), 0, s, a);
+        if (fused) {
+            if (z.P == 8) hipLaunchKernelGGL(chz_fused_kernel<8>, dim3(nwg), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL(chz_fused_kernel<16>, dim3(nwg), dim3(256), 0, s, a);
+        } else {
+            if (z.P == 8) hipLaunchKernelGGL(chz_pfb_fft_kernel<8>, dim3(nwg), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL(chz_pfb_fft_kernel<16>, dim3(nwg), dim3(256), 0, s, a);
+        }
     }
     const uint32_t consumed = nframes * CHZ_D;                        // virtual samples consumed (incl. leftover)
     const uint32_t new_left = (uint32_t)(avail - consumed);
     hipLaunchKernelGGL(chz_carry_kernel, dim3((hist + new_left + 255) / 256), dim3(256), 0, s, d, z.carry[z.carry_cur],
-                       z.carry[z.carry_cur ^ 1], z.carry_len, (uint32_t)nsamp, hist, consumed - leftover + leftover, hist + new_left);
+                       z.carry[z.carry_cur ^ 1], z.carry_len, (uint32_t)nsamp, hist, consumed, hist + new_left);
     if (hipGetLastError() != hipSuccess) return -EIO;
     z.carry_cur ^= 1;
     z.carry_len = hist + new_left;
     z.frames_done += nframes;
-    *chan_iq = z.out; *ld = z.ld; *nframes_out = nframes;
+    if (chan_iq) *chan_iq = z.out;
+    if (ld) *ld = z.ld;
+    *nframes_out = nframes;
     return 0;
 }
 

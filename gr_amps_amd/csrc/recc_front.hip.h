@@ -98,15 +98,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 // v_pk_fma / v_pk_add: measured on MI355X a packed fp32 op issues in ~4.8 cycles per wave against
 // ~4.3 for a scalar one (scripts/ubench_pk.hip), i.e. 1.8x the arithmetic per issue slot, and this
 // kernel is VALU-issue bound.  ~19 instructions per sample instead of ~30.
-__device__ __forceinline__ f2 fm_phase_pair(float4 s, float pr, float pi_)
+// ta, tb = the two conj-products (re, im); everything after them is packed over the two samples
+__device__ __forceinline__ f2 fm_phase_core(f2 ta, f2 tb)
 {
-    const f2 xa = { s.x, s.y }, xb = { s.z, s.w };
-    // t = x * conj(p): (re, im) = (xr*pr + xi*pi, xi*pr - xr*pi), packed over (re, im)
-    const f2 ma = (f2){ s.y, s.x } * (f2){ pi_, -pi_ };
-    const f2 ta = __builtin_elementwise_fma(xa, (f2){ pr, pr }, ma);
-    const f2 mb = (f2){ s.w, s.z } * (f2){ s.y, -s.y };
-    const f2 tb = __builtin_elementwise_fma(xb, (f2){ s.x, s.x }, mb);
-    // from here on packed over the two samples
     const f2 re = { ta.x, tb.x }, im = { ta.y, tb.y };
     const float axa = __builtin_fabsf(ta.x), aya = __builtin_fabsf(ta.y);
     const float axb = __builtin_fabsf(tb.x), ayb = __builtin_fabsf(tb.y);
@@ -136,6 +130,26 @@ __device__ __forceinline__ f2 fm_phase_pair(float4 s, float pr, float pi_)
     return (f2){ __builtin_copysignf(a.x, im.x), __builtin_copysignf(a.y, im.y) };
 }
 
+// t = x * conj(p): (re, im) = (xr*pr + xi*pi, xi*pr - xr*pi), packed over (re, im)
+__device__ __forceinline__ f2 conj_product(f2 x, f2 p)
+{
+    const f2 m = (f2){ x.y, x.x } * (f2){ p.y, -p.y };
+    return __builtin_elementwise_fma(x, (f2){ p.x, p.x }, m);
+}
+
+__device__ __forceinline__ f2 fm_phase_pair(float4 s, float pr, float pi_)
+{
+    const f2 xa = { s.x, s.y }, xb = { s.z, s.w };
+    return fm_phase_core(conj_product(xa, (f2){ pr, pi_ }), conj_product(xb, xa));
+}
+
+// the same discriminator for two INDEPENDENT streams (x0 after p0, x1 after p1): used behind the channelizer's
+// FFT, where a lane owns four channels and the predecessor is the previous frame's value of the same bin
+__device__ __forceinline__ f2 fm_phase_two(f2 x0, f2 p0, f2 x1, f2 p1)
+{
+    return fm_phase_core(conj_product(x0, p0), conj_product(x1, p1));
+}
+
 // Per-wave LDS demod buffers (two, used alternately): 16 floats of history (the tail of the previous
 // tile, written by the previous tile's P1 into THIS buffer) then the 512 floats of the tile; every 8
 // floats padded by one, so the boxcar reads of lane L hit bank 9*L + const (conflict free) and every
@@ -163,7 +177,10 @@ __device__ __forceinline__ float lane63(float v)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-template <int SPS, int DEPTH>
+// BITS = true is the bit-domain form used behind the fused channelizer: the slicer bits of this launch are
+// already in the HBM ring (written by chz_fused_kernel), so a tile is just 16 dwords read from it and only the
+// correlator / emit stages (P3a, P3b) run.
+template <int SPS, int DEPTH, bool BITS = false>
 __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc_front_kernel(FrontArgs a)
 {
     static_assert(SPS >= 2 && SPS <= 16, "samples per symbol");
@@ -247,9 +264,12 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc
     float last_x = 0.f, last_y = 0.f;            // last sample of the previous tile (wave-uniform)
     uint32_t ndet = 0;                           // hits appended by this wave (wave-uniform)
     bool hit_prev = false;                       // the previous tile had a trigger hit (wave-uniform)
-    load_tile(cur, chunk_start - HALO);
+    if constexpr (!BITS) {
+        load_tile(cur, chunk_start - HALO);
 #pragma unroll
-    for (int d = 0; d + 1 < DEPTH; d++) load_tile(nxt[d], chunk_start - HALO + (d + 1) * TILE);   // K >= 1: all exist up to d = 1
+        for (int d = 0; d + 1 < DEPTH; d++) load_tile(nxt[d], chunk_start - HALO + (d + 1) * TILE);   // K >= 1: all exist up to d = 1
+    }
+    const uint32_t *gring32 = (const uint32_t *)(a.gring + (uint64_t)c * a.ring_words);
 
     // k = -2, -1 are the halo tiles [chunk_start-1024, chunk_start): recomputed, never stored or emitted
     for (int k = -2; k < K; k++) {
@@ -257,6 +277,15 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc
         const int slot = (k + 2) & 3;                          // bit-ring slot of this tile
         float *const dcur = s_d + ((k + 2) & 1) * DBUF;        // demod buffer of this tile
         float *const dnxt = s_d + ((k + 3) & 1) * DBUF;        // ... of the next tile (gets our tail as history)
+        if constexpr (BITS) {
+            // the tile's 512 slicer bits come from the HBM ring; samples before the stream are ones (x = 0 -> g = 1)
+            if (lane < TILE / 32) {
+                const int64_t n32 = (int64_t)a.n_done + t0 + 32 * lane;
+                const uint32_t w = n32 < 0 ? ~0u : gring32[(uint64_t)(n32 >> 5) & (2ull * a.ring_words - 1)];
+                s_g[slot * (TILE / 32) + lane] = w;
+                if (slot == 0 && lane < 2) s_g[GW32 + lane] = w;      // mirror of dwords 0,1
+            }
+        } else {
         // ---- P1: prefetch the next tile, demodulate this one into LDS ----
         if (k + DEPTH < K) load_tile(nxt[DEPTH - 1], t0 + DEPTH * TILE);
         float *const dw = dcur + dw_off;
@@ -305,6 +334,7 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc
             ((uint8_t *)s_g)[slot * (TILE / 8) + lane] = (uint8_t)byte;
             if (slot == 0 && lane < 8) ((uint8_t *)s_g)[GW32 * 4 + lane] = (uint8_t)byte;   // mirror of dwords 0,1
         }
+        }   // !BITS
         __builtin_amdgcn_wave_barrier();
         // ---- P3a: bit-parallel exact match of the 74-symbol trigger; publish slicer words ----
         bool hit = false;
@@ -337,7 +367,7 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc
             if (part == 0) {
                 s_m[slot * (TILE / 32) + wq] = acc;
                 const int64_t relw = t0 / 64 + (wq >> 1);      // rel 64-bit word index
-                if (k >= 0 && relw < words_end) {
+                if (!BITS && k >= 0 && relw < words_end) {
                     uint64_t absw = a.n_done / 64 + (uint64_t)relw;
                     uint32_t *g32 = (uint32_t *)(a.gring + (uint64_t)c * a.ring_words + (absw & a.ring_mask));
                     g32[wq & 1] = s_g[slot * (TILE / 32) + wq];
@@ -389,11 +419,13 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc
             }
         }
         hit_prev = hit;
+        if constexpr (!BITS) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            cur[q] = nxt[0][q];
+            for (int q = 0; q < 4; q++) {
+                cur[q] = nxt[0][q];
 #pragma unroll
-            for (int d = 0; d + 1 < DEPTH; d++) nxt[d][q] = nxt[d + 1][q];
+                for (int d = 0; d + 1 < DEPTH; d++) nxt[d][q] = nxt[d + 1][q];
+            }
         }
     }
     if (lane == 0) a.detcount[(uint64_t)c * a.max_chunks + chunk] = ndet < a.det_cap ? ndet : a.det_cap;

@@ -56,6 +56,8 @@ extern "C" {
 
 /* amps_recc_cfg_t.flags */
 #define AMPS_RECC_FLAG_TIME_KERNELS 0x1u /* record HIP events around every kernel (amps_recc_get_timing) */
+#define AMPS_RECC_FLAG_UNFUSED_WIDEBAND 0x4u /* channelizer seam: keep the channel-major intermediate in HBM (two kernels)
+                                               instead of fusing the RECC front end behind the FFT; same results */
 #define AMPS_RECC_FLAG_MAJORITY     0x2u /* decode mode "majority" instead of "reference" (SURVEY.md 8f.2), see below */
 
 /* message classes, the branches of lib/recc_decode_impl.cc:108-168 */
