@@ -244,8 +244,9 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("AMPS_BENCH_FORCE_DIST") == "1":   # the env knob exercises the RCCL path on a 1-GPU box
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
@@ -269,10 +270,11 @@ def main():
         if a.workload == "wideband832":
             out["cpu_baseline"]["sample"] += ("; per channel at 200 ksps, i.e. downstream of the per-channel 299-tap channel filter the reference "
                                                "would also run (G1, ~0.5 GFLOP/s per channel, not timed)")
-    if rank == 0:
-        print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:          # the JSON line is the last thing written (RCCL prints its banner before this)
+        sys.stderr.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
