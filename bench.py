@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--secondary", default="direct832", choices=["none", "direct832", "direct1", "wideband832"],
                     help="a second workload reported under 'secondary' (N=1 only)")
     ap.add_argument("--samples", type=int, default=0, help="per-channel samples per step (0 = workload default)")
+    ap.add_argument("--taps", type=int, default=8, choices=[8, 16], help="wideband832: prototype taps per polyphase branch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -148,7 +149,7 @@ def run_workload(name, a, torch, dev, dist, rank, world, local):
         batch, expected = make_wideband_batch(torch, dev, NW, first_bin, C, 2, seed=rank + 1)
         iq_base = None
         r = capi.Recc(n_channels=C, sps=sps, max_samples=N + 8, max_bursts=max(4096, 2 * expected), device=local, time_kernels=True,
-                      wideband={"channels": 1024, "decim": 512, "taps_per_branch": 8, "first_channel": first_bin})
+                      wideband={"channels": 1024, "decim": 512, "taps_per_branch": a.taps, "first_channel": first_bin})
 
         def step():
             r.push_wideband(batch)
@@ -200,7 +201,7 @@ def run_workload(name, a, torch, dev, dist, rank, world, local):
     if wide:   # dominant kernel = the channelizer; algorithmic bytes = the wideband block read once (14.77 B/symbol)
         kms = tm["ms_channelizer"] / max(1, tm["launches_channelizer"])
         alg_bytes = 8.0 * NW
-        kname = "chz_fused_kernel<8>"
+        kname = "chz_fused_kernel<%d>" % a.taps
         note = ("filter bank + FFT-1024 + FM discriminator + boxcar + slicer in one kernel (~35 flop per input byte): latency/VALU "
                 "bound, not HBM bound; the HBM fraction is what the metric asks for.  Only slicer bits (1/64 of the input) reach HBM; "
                 "the bit-domain correlator (ms_front) and the decode kernels follow")
