@@ -243,6 +243,15 @@ int dispatch_front(uint32_t sps, const FrontArgs &fa, dim3 grid, hipStream_t s)
 }
 
 // the fused chain on channel-major device IQ: front -> carry -> resolve -> capture/decode
+// one workgroup per channel; wide groups when a channel spans more wave segments than 256 lanes cover in one batch
+static void launch_resolve(amps_recc *h, const ResolveArgs &ra, hipStream_t s)
+{
+    if (ra.tiles_per_channel / ra.span + 2 > (uint64_t)RESOLVE_THREADS)
+        hipLaunchKernelGGL(recc_resolve_kernel<RESOLVE_THREADS_WIDE>, dim3(h->C), dim3(RESOLVE_THREADS_WIDE), 0, s, ra);
+    else
+        hipLaunchKernelGGL(recc_resolve_kernel<RESOLVE_THREADS>, dim3(h->C), dim3(RESOLVE_THREADS), 0, s, ra);
+}
+
 int run_iq_device(amps_recc *h, const float2 *iq, uint64_t ld, uint32_t nsamp)
 {
     if (nsamp == 0) return 0;
@@ -288,7 +297,7 @@ int run_iq_device(amps_recc *h, const float2 *iq, uint64_t ld, uint32_t nsamp)
         ra.capq_cap = h->cfg.max_bursts; ra.status = h->status;
         {
             SpanGuard g(h, T_RESOLVE);
-            hipLaunchKernelGGL(recc_resolve_kernel, dim3(h->C), dim3(64), 0, s, ra);
+            launch_resolve(h, ra, s);
         }
         if (int rc = debug_sync(h, "resolve")) return rc;
         CaptureArgs ca{};
@@ -576,7 +585,7 @@ int run_bits_device(amps_recc *h, uint32_t P)
     ra.capq_cap = h->cfg.max_bursts; ra.status = h->status;
     {
         SpanGuard g(h, T_RESOLVE);
-        hipLaunchKernelGGL(recc_resolve_kernel, dim3(h->C), dim3(64), 0, s, ra);
+        launch_resolve(h, ra, s);
     }
     CaptureArgs ca{};
     ca.capq = h->capq; ca.capq_count = h->capq_count; ca.capq_cap = h->cfg.max_bursts; ca.sps = h->sps;

@@ -33,55 +33,102 @@ struct ResolveArgs {
     uint32_t *status;          // bit 1: capture queue overflow
 };
 
-__global__ __launch_bounds__(64) void recc_resolve_kernel(ResolveArgs a)
+constexpr int RESOLVE_THREADS = 256;       // many channels, few segments each
+constexpr int RESOLVE_THREADS_WIDE = 1024; // few channels, thousands of segments each (one channel x 2^26 samples)
+constexpr int RESOLVE_LDS_HITS = 2048;
+
+// One workgroup per channel.  The hit lists of a channel's wave segments are ordered but scattered
+// (up to thousands of segments when one channel is pushed 2^26 samples at a time): 256 (or 1024) lanes compact them into
+// LDS with a block-wide prefix sum (coalesced count loads, independent hit loads), then wave 0 does the hold-off
+// walk -- sequential by nature, but now on LDS instead of a chain of dependent HBM reads (0.72 ms -> see DESIGN.md).
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void recc_resolve_kernel(ResolveArgs a)
 {
-    const int c = blockIdx.x, lane = threadIdx.x;
+    __shared__ uint64_t s_hits[RESOLVE_LDS_HITS];
+    __shared__ uint32_t s_scan[THREADS];
+    __shared__ uint64_t s_acc[RESOLVE_LDS_HITS + 1];               // +1: the pending capture of an earlier push
+    __shared__ uint32_t s_total, s_nacc, s_base;
+    const int c = blockIdx.x, tid = threadIdx.x;
     const uint64_t span_hold = (uint64_t)a.sps * (AMPS_RECC_CAPTURE_SYMS + AMPS_RECC_TRIGGER_SYMS);
     const uint64_t span_done = (uint64_t)a.sps * (AMPS_RECC_CAPTURE_SYMS + 1);
     uint64_t next_allowed = a.next_allowed[c];
     uint64_t pend = a.pending[c];
 
-    auto enqueue = [&](uint64_t nc) {   // called uniformly; lane 0 appends
-        if (lane == 0) {
-            uint32_t slot = atomicAdd(a.capq_count, 1u);
-            if (slot < a.capq_cap) a.capq[slot] = ((uint64_t)c << 40) | nc;
-            else atomicOr(a.status, 2u);
+    // accepted captures are collected in LDS and published with ONE atomicAdd per batch: a global atomic per burst
+    // is a ~0.4 us round trip on the sequential walk
+    uint32_t nacc = 0;                                                // wave 0 only, uniform
+    auto flush = [&]() {                                              // all 256 threads
+        __syncthreads();
+        const uint32_t m = s_nacc;
+        if (m) {
+            if (tid == 0) s_base = atomicAdd(a.capq_count, m);
+            __syncthreads();
+            const uint32_t base = s_base;
+            for (uint32_t i = tid; i < m; i += THREADS) {
+                if (base + i < a.capq_cap) a.capq[base + i] = ((uint64_t)c << 40) | s_acc[i];
+                else atomicOr(a.status, 2u);
+            }
         }
+        __syncthreads();
     };
-
-    if (pend != ~0ull && pend + span_done < a.n_proc) { enqueue(pend); pend = ~0ull; }
+    if (pend != ~0ull && pend + span_done < a.n_proc) {
+        if (tid == 0) s_acc[0] = pend;
+        nacc = 1;
+        pend = ~0ull;
+    }
 
     // segments of channel c: waves floor(c*Tc/span) .. floor((c*Tc + Tc - 1)/span), in stream order
     const uint64_t gs = (uint64_t)c * a.tiles_per_channel;
     const uint32_t nchunks = (uint32_t)((gs + a.tiles_per_channel - 1) / a.span - gs / a.span) + 1;
     const uint32_t *cnt = a.detcount + (uint64_t)c * a.max_chunks;
     const uint64_t *det = a.det + (uint64_t)c * a.max_chunks * a.det_cap;
-    for (uint32_t cb = 0; cb < nchunks; cb += 64) {
-        uint32_t ch = cb + lane;
-        uint32_t n = ch < nchunks ? cnt[ch] : 0u;
-        uint64_t any = __ballot(n != 0);
-        while (any) {                                 // chunks in order, hits in order (both rare)
-            int l = __ffsll((unsigned long long)any) - 1;
-            any &= any - 1;
-            uint32_t nl = __shfl(n, l);
-            const uint64_t *d = det + (uint64_t)(cb + l) * a.det_cap;
-            for (uint32_t b = 0; b < nl; b += 64) {
-                uint64_t e = (b + lane < nl) ? d[b + lane] : 0ull;
-                uint32_t m = nl - b < 64 ? nl - b : 64;
-                for (uint32_t i = 0; i < m; i++) {
-                    uint64_t ei = __shfl(e, (int)i);
-                    uint64_t astart = ei >> 8;
-                    uint32_t last = (uint32_t)(ei & 0xff);
-                    if (astart < next_allowed) continue;      // inside an accepted burst
-                    uint64_t nc = astart + last / 2;          // centre of the run of matching phases
+
+    for (uint32_t cb = 0; cb < nchunks; cb += THREADS) {
+        // ---- compaction of up to 256 segments into LDS, order preserved
+        const uint32_t ch = cb + tid;
+        const uint32_t n = ch < nchunks ? cnt[ch] : 0u;
+        s_scan[tid] = n;
+        __syncthreads();
+        for (int off = 1; off < THREADS; off <<= 1) {       // Hillis-Steele inclusive scan
+            uint32_t v = tid >= off ? s_scan[tid - off] : 0u;
+            __syncthreads();
+            s_scan[tid] += v;
+            __syncthreads();
+        }
+        const uint32_t excl = s_scan[tid] - n;
+        if (tid == THREADS - 1) s_total = s_scan[tid];
+        const uint64_t *d = det + (uint64_t)ch * a.det_cap;
+        for (uint32_t i = 0; i < n; i++) {
+            if (excl + i < RESOLVE_LDS_HITS) s_hits[excl + i] = d[i];
+            else atomicOr(a.status, 1u);                              // more hits than one batch can hold
+        }
+        __syncthreads();
+        // ---- hold-off walk (wave 0): every lane follows the same scalar path
+        if (tid < 64) {
+            const uint32_t total = s_total < RESOLVE_LDS_HITS ? s_total : RESOLVE_LDS_HITS;
+            for (uint32_t b = 0; b < total; b += 64) {                // 64 hits per LDS read, then readlane
+                const uint64_t mine = b + tid < total ? s_hits[b + tid] : 0ull;
+                const uint32_t mlo = (uint32_t)mine, mhi = (uint32_t)(mine >> 32);
+                const uint32_t m = total - b < 64u ? total - b : 64u;
+                for (uint32_t j = 0; j < m; j++) {
+                    const uint64_t ei = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mhi, (int)j) << 32) |
+                                        (uint32_t)__builtin_amdgcn_readlane((int)mlo, (int)j);
+                    const uint64_t astart = ei >> 8;
+                    const uint32_t last = (uint32_t)(ei & 0xff);
+                    if (astart < next_allowed) continue;              // inside an accepted burst
+                    const uint64_t nc = astart + last / 2;            // centre of the run of matching phases
                     next_allowed = nc + span_hold;
-                    if (nc + span_done < a.n_proc) enqueue(nc);
-                    else pend = nc;                           // tail not received yet
+                    if (nc + span_done < a.n_proc) s_acc[nacc++] = nc;    // all lanes store the same value: no branch
+                    else pend = nc;                                   // tail not received yet
                 }
             }
+            if (tid == 0) s_nacc = nacc;
+            nacc = 0;
         }
+        flush();
     }
-    if (lane == 0) { a.next_allowed[c] = next_allowed; a.pending[c] = pend; }
+    if (nchunks == 0) { if (tid == 0) s_nacc = nacc; flush(); }
+    if (tid == 0) { a.next_allowed[c] = next_allowed; a.pending[c] = pend; }
 }
 
 struct CaptureArgs {
