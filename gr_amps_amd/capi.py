@@ -53,6 +53,14 @@ class Timing(C.Structure):
         ("ms_resolve", C.c_double), ("ms_decode", C.c_double), ("ms_carry", C.c_double),
         ("ms_symbols", C.c_double), ("samples_front", C.c_uint64),
         ("ms_channelizer", C.c_double), ("launches_channelizer", C.c_uint32), ("_pad", C.c_uint32),
+        ("ms_xlate", C.c_double),
+    ]
+
+
+class XlateCfg(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("decim", C.c_uint32), ("rate_hz", C.c_double), ("center_hz", C.c_double),
+        ("gain", C.c_double), ("cutoff_hz", C.c_double), ("width_hz", C.c_double),
     ]
 
 
@@ -73,6 +81,7 @@ EXPORTS = (
     "amps_recc_push_iq", "amps_recc_push_wideband", "amps_recc_drain", "amps_recc_debug_demod",
     "amps_recc_get_timing", "amps_recc_reply_words", "amps_recc_debug_channelize",
     "amps_bch_encode_words", "amps_bch_decode_words",
+    "amps_recc_set_xlate", "amps_recc_push_raw", "amps_recc_debug_xlate",
 )
 
 _lib = None
@@ -112,6 +121,9 @@ def load():
     L.amps_recc_get_timing.argtypes = [vp, C.POINTER(Timing), C.c_int]
     L.amps_recc_debug_channelize.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.amps_recc_reply_words.argtypes = [vp, C.POINTER(Reply)]
+    L.amps_recc_set_xlate.argtypes = [vp, C.POINTER(XlateCfg)]
+    L.amps_recc_push_raw.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int]
+    L.amps_recc_debug_xlate.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.amps_bch_encode_words.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, vp]
     L.amps_bch_decode_words.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, vp, vp, vp]
     for name in EXPORTS:
@@ -233,6 +245,39 @@ class Recc:
         rc = load().amps_recc_push_iq(self._h, ptr, ld, nsamp, mem)
         if rc:
             raise AmpsError(rc, "amps_recc_push_iq")
+
+    def set_xlate(self, rate_hz=400e3, center_hz=160e3, decim=2, gain=0.0, cutoff_hz=0.0, width_hz=0.0):
+        """Put the reference flow graph's channel filter (freq_xlating_fir_filter_ccc, grc/recctest.grc:889-937)
+        in front of the IQ seam; zeros select the flow graph's gain / cutoff / transition width."""
+        x = XlateCfg(C.sizeof(XlateCfg), decim, rate_hz, center_hz, gain, cutoff_hz, width_hz)
+        rc = load().amps_recc_set_xlate(self._h, C.byref(x))
+        if rc:
+            raise AmpsError(rc, "amps_recc_set_xlate")
+
+    def push_raw(self, iq, nsamp=None):
+        """like push_iq, at the translate stage's input rate (e.g. the 400 ksps .raw captures of recctest.grc)."""
+        if isinstance(iq, np.ndarray):
+            iq = np.ascontiguousarray(iq, np.complex64).reshape(self.n_channels, -1)
+        ld = iq.shape[1]
+        nsamp = ld if nsamp is None else nsamp
+        ptr, mem, keep = _as_ptr(iq)
+        rc = load().amps_recc_push_raw(self._h, ptr, ld, nsamp, mem)
+        if rc:
+            raise AmpsError(rc, "amps_recc_push_raw")
+
+    def debug_xlate(self, iq):
+        """Translate stage only (test tap): complex64 [C][n] -> complex64 [C][nout]."""
+        if isinstance(iq, np.ndarray):
+            iq = np.ascontiguousarray(iq, np.complex64).reshape(self.n_channels, -1)
+        n = iq.shape[1]
+        ptr, mem, keep = _as_ptr(iq)
+        cap = n + 8
+        out = np.zeros((self.n_channels, cap), np.complex64)
+        no = C.c_size_t(0)
+        rc = load().amps_recc_debug_xlate(self._h, ptr, n, n, mem, _hostptr(out), cap, C.byref(no))
+        if rc:
+            raise AmpsError(rc, "amps_recc_debug_xlate")
+        return out[:, :no.value].copy()
 
     def push_wideband(self, iq):
         if isinstance(iq, np.ndarray):

@@ -17,6 +17,7 @@
 #include "recc_resolve.hip.h"
 #include "recc_symbols.hip.h"
 #include "recc_channelizer.hip.h"
+#include "recc_xlate.hip.h"
 
 static_assert(sizeof(amps_recc_burst_t) == AMPS_RECC_BURST_BYTES, "record layout is part of the ABI");
 static_assert(sizeof(amps_recc_burst_t) % 8 == 0, "records are copied as dwords");
@@ -34,7 +35,7 @@ using namespace amps;
         }                                                                               \
     } while (0)
 
-enum { T_FRONT = 0, T_RESOLVE, T_DECODE, T_CARRY, T_SYMBOLS, T_CHANNELIZER, T_COUNT };
+enum { T_FRONT = 0, T_RESOLVE, T_DECODE, T_CARRY, T_SYMBOLS, T_CHANNELIZER, T_XLATE, T_COUNT };
 
 struct TimedSpan { hipEvent_t a, b; int tag; uint64_t samples; };
 
@@ -70,6 +71,9 @@ struct amps_recc {
 
     // ---- channelizer seam ----
     ChannelizerState chz;
+
+    // ---- translate seam (recctest.grc channel filter) ----
+    XlateState xl;
 
     // ---- symbol seam ----
     uint8_t *symbuf = nullptr;
@@ -178,6 +182,8 @@ int reset_state(amps_recc *h)
     h->n_done = 0;
     h->r_prev = 0;
     int rc = channelizer_reset(h->chz, s);
+    if (rc) return rc;
+    rc = xlate_reset(h->xl, s);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(s));
     return 0;
@@ -429,6 +435,7 @@ void amps_recc_destroy(amps_recc_t *h)
     if (h->rec_host) (void)hipHostFree(h->rec_host);
     if (h->hdr_host) (void)hipHostFree(h->hdr_host);
     channelizer_destroy(h->chz);
+    xlate_destroy(h->xl);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -626,6 +633,65 @@ int amps_recc_push_wideband(amps_recc_t *h, const float *iq, size_t nsamp, int m
     return run_iq_device(h, chan_iq, ld, nout);
 }
 
+int amps_recc_set_xlate(amps_recc_t *h, const amps_recc_xlate_cfg_t *x)
+{
+    if (!h || !x || x->struct_size != sizeof(amps_recc_xlate_cfg_t)) return -EINVAL;
+    if (!h->carry[0]) return -ENOSYS;                       // the IQ seam must be configured
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (x->decim == 0) { xlate_destroy(h->xl); return 0; }
+    // defaults = the flow graph's values (grc/recctest.grc:115-155, 889-937)
+    const double gain = x->gain != 0.0 ? x->gain : 3.0;
+    const double cutoff = x->cutoff_hz != 0.0 ? x->cutoff_hz : 10e3;
+    const double width = x->width_hz != 0.0 ? x->width_hz : 4.5e3;
+    if (!(x->rate_hz > 0.0) || !(cutoff > 0.0) || !(width > 0.0)) return -EINVAL;
+    // the filtered stream must arrive at the symbol rate the handle was built for
+    const double out_rate = x->rate_hz / x->decim;
+    if (std::fabs(out_rate - 20e3 * h->sps) > 1e-6 * out_rate) return -EINVAL;
+    std::vector<float> taps = xlate_design_taps(gain, x->rate_hz, cutoff, width);
+    return xlate_create(h->xl, h->C, x->decim, h->cfg.max_samples_per_push, x->rate_hz, x->center_hz, taps, h->stream);
+}
+
+int amps_recc_push_raw(amps_recc_t *h, const float *iq, size_t ld, size_t nsamp, int mem)
+{
+    if (!h) return -EINVAL;
+    if (!h->xl.enabled) return -ENOSYS;
+    if (nsamp == 0) return 0;
+    if (!iq || ld < nsamp) return -EINVAL;
+    HIP_TRY(hipSetDevice(h->device));
+    const float2 *f = nullptr;
+    uint64_t fld = 0;
+    uint32_t nout = 0;
+    int rc;
+    {
+        SpanGuard g(h, T_XLATE, nsamp);
+        rc = xlate_run(h->xl, (const float2 *)iq, ld, nsamp, mem, h->stream, &f, &fld, &nout);
+    }
+    if (rc) return rc;
+    if (int rc2 = debug_sync(h, "xlate")) return rc2;
+    if (nout == 0) return 0;
+    return run_iq_device(h, f, fld, nout);
+}
+
+int amps_recc_debug_xlate(amps_recc_t *h, const float *iq, size_t ld, size_t nsamp, int mem, float *out, size_t out_ld, size_t *nout)
+{
+    if (!h || !iq || !out || !nout || ld < nsamp) return -EINVAL;
+    if (!h->xl.enabled) return -ENOSYS;
+    HIP_TRY(hipSetDevice(h->device));
+    const float2 *f = nullptr;
+    uint64_t fld = 0;
+    uint32_t n = 0;
+    int rc = xlate_run(h->xl, (const float2 *)iq, ld, nsamp, mem, h->stream, &f, &fld, &n);
+    if (rc) return rc;
+    *nout = n;
+    if (n > out_ld) return -E2BIG;
+    if (n)
+        HIP_TRY(hipMemcpy2DAsync(out, out_ld * sizeof(float2), f, fld * sizeof(float2), (size_t)n * sizeof(float2), h->C,
+                                 hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 int amps_recc_drain(amps_recc_t *h, amps_recc_burst_t *out, size_t cap, size_t *nout)
 {
     if (!h || !nout) return -EINVAL;
@@ -738,6 +804,7 @@ int amps_recc_get_timing(amps_recc_t *h, amps_recc_timing_t *t, int reset)
     t->ms_decode = h->ms[T_DECODE];
     t->ms_carry = h->ms[T_CARRY];
     t->ms_symbols = h->ms[T_SYMBOLS];
+    t->ms_xlate = h->ms[T_XLATE];
     t->samples_front = h->samples_front;
     if (reset) {
         for (double &m : h->ms) m = 0;

@@ -128,7 +128,7 @@ __device__ __forceinline__ void chz_frame(cf2 (&line)[4][P], const float (&coef)
 template <int P>
 __global__ __launch_bounds__(256) void chz_pfb_fft_kernel(ChzArgs a)
 {
-    constexpr int M = CHZ_M, D = CHZ_D, L = P * M;
+    constexpr int M = CHZ_M, D = CHZ_D;
     __shared__ cf2 bufA[CHZ_M];
     __shared__ cf2 bufB[CHZ_M];
     const int t = threadIdx.x;

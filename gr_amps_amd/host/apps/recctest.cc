@@ -2,6 +2,8 @@
 // as a stand-alone program.  Modes:
 //   recctest syms <file.u8>  [chunk]   u8 0/1 symbol file -> amps.recc -> amps.recc_decode
 //   recctest iq   <file.fc32> [chunk]  200 ksps interleaved fc32 -> amps.recc_fused -> amps.recc_decode
+//   recctest raw  <file.fc32> [chunk] [center_hz]   the flow graph's own capture format (grc/recctest.grc:591): 400 ksps fc32,
+//                                      channel at center_hz (default +160 kHz, :889-937) -> channel filter + fused chain on the GPU
 // Every message published on recc_decode's output ports is printed as one text line, which is what
 // tests/test_gpu_host_blocks.py compares with the oracle.
 #include <amps/recc.h>
@@ -53,7 +55,7 @@ struct sink : gr::block {   // prints what ampsbs.grc would route to focc / fvc 
 
 int main(int argc, char **argv)
 {
-    if (argc < 3) { std::fprintf(stderr, "usage: %s syms|iq <file> [chunk]\n", argv[0]); return 2; }
+    if (argc < 3) { std::fprintf(stderr, "usage: %s syms|iq|raw <file> [chunk] [center_hz]\n", argv[0]); return 2; }
     const std::string mode = argv[1];
     const int chunk = argc > 3 ? std::atoi(argv[3]) : 4096;
     std::ifstream f(argv[2], std::ios::binary);
@@ -73,7 +75,8 @@ int main(int argc, char **argv)
                 if (src->work(n, ins, outs) != 0) return 1;
             }
         } else {
-            auto src = gr::amps::recc_fused::make(10);
+            const double center = argc > 4 ? std::atof(argv[4]) : 160e3;
+            auto src = mode == "raw" ? gr::amps::recc_fused::make(10, 400e3, center, 2) : gr::amps::recc_fused::make(10);
             gr::msg_connect(src, "records", dec, "records");
             const size_t ns = data.size() / 8;
             for (size_t off = 0; off < ns; off += (size_t)chunk) {

@@ -4,6 +4,9 @@
 // (200 ksps for the flow graphs as wired); output: the same "bursts" message port as gr::amps::recc,
 // so amps_recc_decode connects to it unchanged.  It additionally publishes the already decoded
 // record on port "records" (blob of amps_recc_burst_t).
+// With xlate_rate_hz > 0 it also absorbs the flow graph's channel filter (freq_xlating_fir_filter_ccc with the
+// firdes.low_pass taps, grc/recctest.grc:889-937, :115-155): the input is then the raw capture rate (400 ksps in
+// recctest.grc) with the channel at xlate_center_hz, and xlate_rate_hz / xlate_decim = samples_per_symbol * 20 kHz.
 #pragma once
 #include <amps/api.h>
 
@@ -13,7 +16,7 @@ namespace amps {
 class AMPS_API recc_fused : virtual public gr::sync_block {
 public:
     typedef AMPS_SPTR<recc_fused> sptr;
-    static sptr make(int samples_per_symbol = 10);
+    static sptr make(int samples_per_symbol = 10, double xlate_rate_hz = 0.0, double xlate_center_hz = 0.0, int xlate_decim = 2);
 };
 
 } // namespace amps

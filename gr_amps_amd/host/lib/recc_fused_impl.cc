@@ -11,11 +11,13 @@ namespace amps {
 
 class recc_fused_impl : public recc_fused {
     amps_recc_t *d_handle;
+    bool d_raw;
     static const int kMaxPush = 1 << 20;
 
 public:
-    explicit recc_fused_impl(int sps)
-        : gr::sync_block("recc_fused", gr::io_signature::make(1, 1, 2 * sizeof(float)), gr::io_signature::make(0, 0, 0)), d_handle(nullptr)
+    recc_fused_impl(int sps, double xlate_rate, double xlate_center, int xlate_decim)
+        : gr::sync_block("recc_fused", gr::io_signature::make(1, 1, 2 * sizeof(float)), gr::io_signature::make(0, 0, 0)), d_handle(nullptr),
+          d_raw(xlate_rate > 0.0)
     {
         amps_recc_cfg_t cfg = {};
         cfg.struct_size = sizeof(cfg);
@@ -26,6 +28,18 @@ public:
         cfg.device = -1;
         int rc = amps_recc_create(&d_handle, &cfg);
         if (rc != 0) throw std::runtime_error(std::string("amps::recc_fused: ") + amps_recc_strerror(rc));
+        if (d_raw) {
+            amps_recc_xlate_cfg_t x = {};
+            x.struct_size = sizeof(x);
+            x.decim = (uint32_t)xlate_decim;
+            x.rate_hz = xlate_rate;
+            x.center_hz = xlate_center;
+            rc = amps_recc_set_xlate(d_handle, &x);
+            if (rc != 0) {
+                amps_recc_destroy(d_handle);
+                throw std::runtime_error(std::string("amps::recc_fused (xlate): ") + amps_recc_strerror(rc));
+            }
+        }
         message_port_register_out(pmt::mp("records"));
     }
     ~recc_fused_impl() { amps_recc_destroy(d_handle); }
@@ -37,7 +51,8 @@ public:
         while (done < noutput_items) {
             int n = noutput_items - done;
             if (n > kMaxPush) n = kMaxPush;
-            int rc = amps_recc_push_iq(d_handle, in + 2 * (size_t)done, (size_t)n, (size_t)n, AMPS_MEM_HOST);
+            int rc = d_raw ? amps_recc_push_raw(d_handle, in + 2 * (size_t)done, (size_t)n, (size_t)n, AMPS_MEM_HOST)
+                           : amps_recc_push_iq(d_handle, in + 2 * (size_t)done, (size_t)n, (size_t)n, AMPS_MEM_HOST);
             if (rc != 0) { std::fprintf(stderr, "amps::recc_fused: %s\n", amps_recc_strerror(rc)); return WORK_DONE; }
             amps_recc_burst_t recs[64];
             size_t nrec = 0;
@@ -51,7 +66,10 @@ public:
     }
 };
 
-recc_fused::sptr recc_fused::make(int samples_per_symbol) { return gnuradio::get_initial_sptr(new recc_fused_impl(samples_per_symbol)); }
+recc_fused::sptr recc_fused::make(int samples_per_symbol, double xlate_rate_hz, double xlate_center_hz, int xlate_decim)
+{
+    return gnuradio::get_initial_sptr(new recc_fused_impl(samples_per_symbol, xlate_rate_hz, xlate_center_hz, xlate_decim));
+}
 
 } // namespace amps
 } // namespace gr

@@ -148,6 +148,7 @@ typedef struct amps_recc_timing {
     double   ms_channelizer;   /* polyphase channelizer kernel (wideband seam)                            */
     uint32_t launches_channelizer;
     uint32_t _pad;
+    double   ms_xlate;         /* translate seam: mixing + channel FIR + decimation kernel                */
 } amps_recc_timing_t;
 
 typedef struct amps_recc amps_recc_t; /* opaque; owns device buffers + per-channel stream state */
@@ -182,6 +183,27 @@ int amps_recc_push_iq(amps_recc_t *h, const float *iq, size_t ld, size_t nsamp, 
 /* channelizer seam: one wideband interleaved fc32 stream (fs = M * 30 kHz) -> polyphase
  * channelizer -> the same fused path on every active channel.  nsamp wideband samples. */
 int amps_recc_push_wideband(amps_recc_t *h, const float *iq, size_t nsamp, int mem);
+
+/* translate seam: the channel filter the reference's test flow graph wires in front of the
+ * chain -- freq_xlating_fir_filter_ccc(decim, firdes.low_pass(gain, rate, cutoff, width), center, rate),
+ * grc/recctest.grc:889-937 with taps :115-155 -- so that its ".raw" fc32 captures (400 ksps, channel at
+ * +-160 kHz, :591) can be pushed directly.  rate_hz / decim must equal samples_per_symbol * 20 kHz.
+ * gain / cutoff_hz / width_hz = 0 select the flow graph's 3.0 / 10 kHz / 4.5 kHz (299 taps at 400 ksps).
+ * decim = 0 removes the stage.  Resets nothing else; call before the first push. */
+typedef struct amps_recc_xlate_cfg {
+    uint32_t struct_size;
+    uint32_t decim;            /* 1, 2 or 4 */
+    double   rate_hz;          /* input sample rate */
+    double   center_hz;        /* channel centre relative to the input's centre, |center| <= rate */
+    double   gain, cutoff_hz, width_hz;
+} amps_recc_xlate_cfg_t;
+int amps_recc_set_xlate(amps_recc_t *h, const amps_recc_xlate_cfg_t *x);
+/* like amps_recc_push_iq but iq is [n_channels][ld] at rate_hz; every channel uses the same centre.
+ * nsamp <= decim * max_samples_per_push; any nsamp (leftover samples wait for the next push). */
+int amps_recc_push_raw(amps_recc_t *h, const float *iq, size_t ld, size_t nsamp, int mem);
+/* test tap: run only the translate stage (continuing its stream); out is host [n_channels][out_ld] fc32 */
+int amps_recc_debug_xlate(amps_recc_t *h, const float *iq, size_t ld, size_t nsamp, int mem,
+                          float *out, size_t out_ld, size_t *nout);
 
 /* Synchronise the handle's stream and copy out the decoded bursts accumulated since the last
  * drain, sorted by (channel, position).  -ENOSPC if the device list overflowed max_bursts

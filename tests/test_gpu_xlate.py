@@ -1,0 +1,123 @@
+"""Translate seam: the channel filter of grc/recctest.grc -- freq_xlating_fir_filter_ccc with the
+firdes.low_pass taps (grc/recctest.grc:889-937, :115-155) -- on the GPU, in front of the fused IQ seam, so that the
+flow graph's 400 ksps ".raw" captures can be pushed as they are.
+
+Float stage: compared with the oracle's restatement of the GNU Radio block (composite complex taps + rotator, fp32) and
+with the exact formula in float64, tolerance stated below.  Downstream of it the comparison is word-level and bit-exact."""
+import numpy as np
+import pytest
+
+import oracle
+from gr_amps_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+# |y_gpu - y_exact| for unit-amplitude input through taps of DC gain 3: the kernel mixes in fp32 (phase exact to 2^-24
+# turn) and accumulates 299 fp32 fma; the oracle's composite-tap/rotator arithmetic differs from the exact result by
+# about as much.  Both bounds are absolute, on samples of magnitude <= 3.
+TOL_EXACT = 2.0e-5
+TOL_ORACLE = 6.0e-5
+
+
+def _raw400(seed, n=2 * 400000, nb=12, fc=160e3):
+    iq400, truth = synth.make_channel_block(n, nb, seed=seed, sps=20, spacing=(3456 + 74 + 4096 + 600) * 20)
+    k = np.arange(iq400.size)
+    return (iq400 * np.exp(2j * np.pi * fc * k / 400e3)).astype(np.complex64), truth
+
+
+def _exact(x, taps, fc, fs, decim):
+    n = np.arange(x.size)
+    z = x.astype(np.complex128) * np.exp(-2j * np.pi * fc * n / fs)
+    full = np.convolve(z, np.asarray(taps, np.float64))[: x.size]
+    return full[::decim][: x.size // decim]
+
+
+@pytest.mark.parametrize("fc", [160e3, -160e3, 37.5e3])
+def test_xlate_matches_reference_block(gpu, fc):
+    rng = np.random.default_rng(7)
+    n = 50000
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64) * np.float32(0.5)
+    taps = oracle.firdes_low_pass(3, 400e3, 10e3, 4.5e3)
+    assert len(taps) == 299
+    with capi.Recc(n_channels=1, sps=10, max_samples=n, max_bursts=4) as r:
+        r.set_xlate(rate_hz=400e3, center_hz=fc, decim=2)
+        y = r.debug_xlate(x[None, :])[0]
+    assert y.size == n // 2
+    e = _exact(x, taps, fc, 400e3, 2)
+    assert np.abs(y - e).max() <= TOL_EXACT, np.abs(y - e).max()
+    ref = oracle.freq_xlating_fir(x, taps, fc, 400e3, 2)
+    assert np.abs(y - ref).max() <= TOL_ORACLE, np.abs(y - ref).max()
+
+
+@pytest.mark.parametrize("decim,sps", [(1, 10), (4, 5)])
+def test_xlate_other_decimations(gpu, decim, sps):
+    rng = np.random.default_rng(8)
+    n = 30001
+    fs = 20e3 * sps * decim
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    with capi.Recc(n_channels=2, sps=sps, max_samples=n, max_bursts=4) as r:
+        r.set_xlate(rate_hz=fs, center_hz=0.11 * fs, decim=decim, gain=1.0, cutoff_hz=12e3, width_hz=6e3)
+        y = r.debug_xlate(np.stack([x, x[::-1]]))
+    taps = oracle.firdes_low_pass(1.0, fs, 12e3, 6e3)
+    assert np.abs(y[0] - _exact(x, taps, 0.11 * fs, fs, decim)).max() <= TOL_EXACT
+    assert np.abs(y[1] - _exact(x[::-1], taps, 0.11 * fs, fs, decim)).max() <= TOL_EXACT
+
+
+@pytest.mark.parametrize("blocks", [[1, 2, 3, 298, 299, 300, 4097], [2047, 2049, 1, 1, 1], [7777] * 5])
+def test_xlate_streaming_is_bitwise(gpu, blocks):
+    """Pushing in ragged blocks (odd sizes leave a sample waiting for the decimator) gives the same bits as one push:
+    the mixer phase is a function of the absolute sample index, the carry holds the filter history."""
+    rng = np.random.default_rng(9)
+    n = sum(blocks)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    with capi.Recc(n_channels=1, sps=10, max_samples=n, max_bursts=4) as r:
+        r.set_xlate(rate_hz=400e3, center_hz=-160e3, decim=2)
+        whole = r.debug_xlate(x[None, :])[0]
+        r.reset()
+        parts, o = [], 0
+        for b in blocks:
+            parts.append(r.debug_xlate(x[None, o:o + b])[0])
+            o += b
+    got = np.concatenate(parts)
+    assert got.size == whole.size == n // 2
+    assert np.array_equal(got.view(np.uint32), whole.view(np.uint32))
+
+
+def test_raw400_words_equal_reference_cpu_chain(gpu):
+    """The whole recctest.grc chain from the 400 ksps capture: oracle = restated G1..G4 + R2..R8 (chain_iq400); product =
+    push_raw (GPU channel filter + fused seam).  The two channel filters agree to ~1e-5, the words must agree exactly."""
+    n_ref = n_gpu = 0
+    for seed in range(3):
+        iq400, truth = _raw400(700 + seed)
+        ref = oracle.chain_iq400(iq400, 160e3, chunk=4096)
+        with capi.Recc(n_channels=1, sps=10, max_samples=iq400.size // 2, max_bursts=64) as r:
+            r.set_xlate(rate_hz=400e3, center_hz=160e3, decim=2)
+            for part in np.array_split(iq400, 5):          # ragged pushes
+                r.push_raw(part[None, :])
+            got = r.drain()
+        assert len(got) == len(truth)
+        by_min = {g["min"]: g for g in got}
+        for rr in ref:
+            assert rr["min"] in by_min, "reference decoded a burst the GPU path missed"
+            g = by_min[rr["min"]]
+            assert np.array_equal(rr["word_raw"], g["word_raw"])
+            assert np.array_equal(rr["word_dec"], g["word_dec"])
+            assert np.array_equal(rr["valid"], g["valid"]) and np.array_equal(rr["dcc"], g["dcc"])
+            for f in ("msg_class", "a_MIN1", "b_MIN2", "esn", "dialed", "min"):
+                assert rr[f] == g[f], f
+        n_ref += len(ref)
+        n_gpu += len(got)
+    assert n_ref >= 0.5 * n_gpu, (n_ref, n_gpu)
+
+
+def test_xlate_argument_errors(gpu):
+    with capi.Recc(n_channels=1, sps=10, max_samples=4096, max_bursts=4) as r:
+        with pytest.raises(capi.AmpsError):
+            r.push_raw(np.zeros((1, 16), np.complex64))                  # stage not configured
+        with pytest.raises(capi.AmpsError):
+            r.set_xlate(rate_hz=400e3, center_hz=160e3, decim=4)         # 100 ksps != 10 samples/symbol
+        with pytest.raises(capi.AmpsError):
+            r.set_xlate(rate_hz=400e3, center_hz=160e3, decim=3)
+        r.set_xlate(rate_hz=400e3, center_hz=160e3, decim=2)
+        with pytest.raises(capi.AmpsError):
+            r.push_raw(np.zeros((1, 2 * 4096 + 2), np.complex64))        # more than decim * max_samples
