@@ -43,7 +43,7 @@ class Cfg(C.Structure):
         ("max_samples_per_push", C.c_uint32), ("max_bursts", C.c_uint32), ("device", C.c_int32),
         ("flags", C.c_uint32), ("wideband_channels", C.c_uint32), ("wideband_decim", C.c_uint32),
         ("wideband_taps_per_branch", C.c_uint32), ("wideband_first_channel", C.c_uint32),
-        ("_reserved", C.c_uint32), ("stream", C.c_void_p),
+        ("sync_tolerance", C.c_uint32), ("stream", C.c_void_p),
     ]
 
 
@@ -155,7 +155,7 @@ class Recc:
     """One handle = `n_channels` independent RECC receivers on one MI355X."""
 
     def __init__(self, n_channels=1, sps=10, max_samples=0, max_bursts=1024, device=-1, time_kernels=False,
-                 stream=None, wideband=None, majority=False, unfused_wideband=False):
+                 stream=None, wideband=None, majority=False, unfused_wideband=False, sync_tolerance=0):
         L = load()
         cfg = Cfg()
         cfg.struct_size = C.sizeof(Cfg)
@@ -167,6 +167,7 @@ class Recc:
         cfg.flags = ((FLAG_TIME_KERNELS if time_kernels else 0) | (FLAG_MAJORITY if majority else 0)
                      | (FLAG_UNFUSED_WIDEBAND if unfused_wideband else 0))
         cfg.stream = stream
+        cfg.sync_tolerance = sync_tolerance
         if wideband:
             cfg.wideband_channels = wideband["channels"]
             cfg.wideband_decim = wideband["decim"]

@@ -221,6 +221,7 @@ int front_blocks_per_cu_for(uint32_t sps)
 }
 template <int SPS> void launch_front(const FrontArgs &fa, dim3 grid, hipStream_t s)
 {
+    if (fa.tol) { hipLaunchKernelGGL((recc_front_kernel<SPS, 1, false, true>), grid, dim3(256), 0, s, fa); return; }
     switch (front_depth()) {
     case 3: hipLaunchKernelGGL((recc_front_kernel<SPS, 3>), grid, dim3(256), 0, s, fa); break;
     case 2: hipLaunchKernelGGL((recc_front_kernel<SPS, 2>), grid, dim3(256), 0, s, fa); break;
@@ -277,6 +278,7 @@ int run_iq_device(amps_recc *h, const float2 *iq, uint64_t ld, uint32_t nsamp)
         fa.r_prev = h->r_prev; fa.avail = avail; fa.P = P; fa.tiles_per_channel = Tc; fa.n_channels = h->C; fa.span = span;
         fa.n_done = h->n_done; fa.gring = h->gring; fa.ring_mask = h->ring_words - 1; fa.ring_words = h->ring_words;
         fa.det = h->det; fa.detcount = h->detcount; fa.max_chunks = h->max_chunks; fa.det_cap = h->det_cap;
+        fa.tol = h->cfg.sync_tolerance;
         fa.status = h->status; fa.dbg_d = h->dbg_d; fa.dbg_S = h->dbg_S; fa.dbg_channel = 0;
         SpanGuard g(h, T_FRONT, P);
         if (debug_sync_enabled())
@@ -355,6 +357,7 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
     if (cfg->struct_size != sizeof(amps_recc_cfg_t)) return -EINVAL;
     if (cfg->n_channels < 1 || cfg->max_bursts < 1) return -EINVAL;
     if (cfg->max_samples_per_push && !sps_supported(cfg->samples_per_symbol)) return -EINVAL;
+    if (cfg->sync_tolerance > AMPS_RECC_MAX_SYNC_TOLERANCE) return -EINVAL;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return -ENODEV;
     int dev = cfg->device;
@@ -580,9 +583,11 @@ int run_bits_device(amps_recc *h, uint32_t P)
     fa.r_prev = 0; fa.avail = P; fa.P = P; fa.tiles_per_channel = Tc; fa.n_channels = h->C; fa.span = span;
     fa.n_done = h->n_done; fa.gring = h->gring; fa.ring_mask = h->ring_words - 1; fa.ring_words = h->ring_words;
     fa.det = h->det; fa.detcount = h->detcount; fa.max_chunks = h->max_chunks; fa.det_cap = h->det_cap; fa.status = h->status;
+    fa.tol = h->cfg.sync_tolerance;
     {
         SpanGuard g(h, T_FRONT, P);
-        hipLaunchKernelGGL((recc_front_kernel<3, 1, true>), dim3((nwaves + 3) / 4), dim3(256), 0, s, fa);
+        if (fa.tol) hipLaunchKernelGGL((recc_front_kernel<3, 1, true, true>), dim3((nwaves + 3) / 4), dim3(256), 0, s, fa);
+        else hipLaunchKernelGGL((recc_front_kernel<3, 1, true>), dim3((nwaves + 3) / 4), dim3(256), 0, s, fa);
     }
     HIP_TRY(hipMemsetAsync(h->capq_count, 0, sizeof(uint32_t), s));
     ResolveArgs ra{};

@@ -87,6 +87,7 @@ struct FrontArgs {
     float    *dbg_d;         // optional taps for channel dbg_channel: d and S of rel samples [0,P)
     float    *dbg_S;
     uint32_t dbg_channel;
+    uint32_t tol;            // TOL kernels: accepted mismatching trigger symbols (cfg.sync_tolerance)
 };
 
 typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));  // two fc32 samples, 8-byte aligned
@@ -180,7 +181,10 @@ __device__ __forceinline__ float lane63(float v)
 // BITS = true is the bit-domain form used behind the fused channelizer: the slicer bits of this launch are
 // already in the HBM ring (written by chz_fused_kernel), so a tile is just 16 dwords read from it and only the
 // correlator / emit stages (P3a, P3b) run.
-template <int SPS, int DEPTH, bool BITS = false>
+// TOL = true replaces the exact trigger match by "at most a.tol of the 74 symbols differ" (a
+// divergence from the reference's memmem, off by default): no prefilter is sound then, so every tile pays a
+// bit-sliced population count over all 74 taps (~350 instructions per lane per tile instead of ~25).
+template <int SPS, int DEPTH, bool BITS = false, bool TOL = false>
 __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc_front_kernel(FrontArgs a)
 {
     static_assert(SPS >= 2 && SPS <= 16, "samples per symbol");
@@ -344,8 +348,44 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc
                 x &= (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
                 return x;
             };
-            // prefilter: the last 16 symbols (all inside the word-sync part), 4 taps per lane
             uint32_t acc = ~0u;
+            if constexpr (TOL) {
+                // each lane of the quad counts the mismatches of its 18-19 taps in five bit planes (32 positions at
+                // once), the quad adds its four counters, and the 7-bit sums are compared with a.tol plane by plane
+                const int bitbase = slot * TILE + 32 * wq;
+                uint32_t cnt[7] = { 0u, 0u, 0u, 0u, 0u, 0u, 0u };
+                for (int i = part; i < TRIG; i += 4) {
+                    const int B = (bitbase - SPS * (TRIG - 1 - i)) & (4 * TILE - 1);
+                    const int qd = B >> 5;
+                    uint32_t m = ~(__builtin_amdgcn_alignbit(s_g[qd + 1], s_g[qd], B & 31) ^ trig_xor(i));   // 1 = differs
+#pragma unroll
+                    for (int pl = 0; pl < 5; pl++) { const uint32_t cy = cnt[pl] & m; cnt[pl] ^= m; m = cy; }
+                }
+#pragma unroll
+                for (int step = 0; step < 2; step++) {
+                    uint32_t cy = 0u;
+#pragma unroll
+                    for (int pl = 0; pl < 5 + step; pl++) {
+                        const uint32_t o = step == 0 ? (uint32_t)__builtin_amdgcn_mov_dpp((int)cnt[pl], 0xB1, 0xF, 0xF, true)    // lane ^ 1
+                                                     : (uint32_t)__builtin_amdgcn_mov_dpp((int)cnt[pl], 0x4E, 0xF, 0xF, true);   // lane ^ 2
+                        const uint32_t x = cnt[pl] ^ o;
+                        const uint32_t sum = x ^ cy;
+                        cy = (cnt[pl] & o) | (x & cy);
+                        cnt[pl] = sum;
+                    }
+                    cnt[5 + step] = cy;
+                }
+                uint32_t gt = 0u, eq = ~0u;
+#pragma unroll
+                for (int pl = 6; pl >= 0; pl--) {
+                    const uint32_t kb = 0u - ((a.tol >> pl) & 1u);
+                    gt |= eq & cnt[pl] & ~kb;
+                    eq &= ~(cnt[pl] ^ kb);
+                }
+                acc = ~gt;
+                hit = __ballot(acc != 0) != 0;
+            } else {
+            // prefilter: the last 16 symbols (all inside the word-sync part), 4 taps per lane
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int qd = (pre_q0[u] + slot * (TILE / 32)) & (GW32 - 1);
@@ -364,6 +404,7 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc
                 acc = and_quad(acc);
                 hit = __ballot(acc != 0) != 0;
             }
+            }   // !TOL
             if (part == 0) {
                 s_m[slot * (TILE / 32) + wq] = acc;
                 const int64_t relw = t0 / 64 + (wq >> 1);      // rel 64-bit word index

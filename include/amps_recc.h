@@ -120,6 +120,9 @@ typedef struct amps_recc_burst {
 } amps_recc_burst_t;
 #define AMPS_RECC_BURST_BYTES 728
 
+/* beyond ~8 wrong symbols the dotting pattern shifted by one bit period starts to pass as a trigger */
+#define AMPS_RECC_MAX_SYNC_TOLERANCE 8
+
 typedef struct amps_recc_cfg {
     uint32_t struct_size;          /* sizeof(amps_recc_cfg_t), for ABI evolution                          */
     uint32_t n_channels;           /* independent RECC instances handled per push (>=1)                   */
@@ -132,7 +135,9 @@ typedef struct amps_recc_cfg {
     uint32_t wideband_decim;       /* channelizer seam: D input samples per output frame (M % D == 0)     */
     uint32_t wideband_taps_per_branch; /* prototype length = taps_per_branch * M                         */
     uint32_t wideband_first_channel;   /* first FFT bin that is an active RECC channel                    */
-    uint32_t _reserved;
+    uint32_t sync_tolerance;       /* IQ / wideband seams: accept a trigger with up to this many of its 74
+                                    * symbols wrong.  0 = exact match, the reference's memmem
+                                    * (lib/recc_impl.cc:118) -- keep 0 for parity runs.  <= AMPS_RECC_MAX_SYNC_TOLERANCE */
     void    *stream;               /* hipStream_t to launch on, NULL = library-owned stream               */
 } amps_recc_cfg_t;
 

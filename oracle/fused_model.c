@@ -61,6 +61,7 @@ struct orc_fused {
     int      have_pending;
     uint64_t pending_nc;
     uint8_t  trig[AMPS_RECC_TRIGGER_SYMS];
+    int      tol;             /* accepted mismatching symbols of the 74 (0 = exact match = reference behaviour) */
 };
 
 orc_fused_t *orc_fused_new(uint32_t channel, int sps)
@@ -75,6 +76,7 @@ void orc_fused_free(orc_fused_t *f)
     if (!f) return;
     free(f->x); free(f->d); free(f->S); free(f->g); free(f->M); free(f);
 }
+void orc_fused_set_tolerance(orc_fused_t *f, int k) { f->tol = k < 0 ? 0 : k; }
 size_t orc_fused_processed(const orc_fused_t *f) { return f->n_done; }
 const float *orc_fused_demod(const orc_fused_t *f) { return f->d; }
 const float *orc_fused_soft(const orc_fused_t *f) { return f->S; }
@@ -135,12 +137,13 @@ size_t orc_fused_push(orc_fused_t *f, const float *iq, size_t n, amps_recc_burst
         f->S[i] = s;
         f->g[i] = s >= 0.0f ? 1 : 0;
     }
-    /* exact 74-symbol trigger test ending at sample i */
+    /* 74-symbol trigger test ending at sample i: at most `tol` symbols may differ (tol = 0: the reference's exact
+     * memmem, lib/recc_impl.cc:118) */
     for (size_t i = lo; i < hi; i++) {
-        int ok = 1;
-        for (int k = 0; k < T && ok; k++)
-            if (gbit(f, (int64_t)i - (int64_t)sps * (T - 1 - k)) != f->trig[k]) ok = 0;
-        f->M[i] = (uint8_t)ok;
+        int bad = 0;
+        for (int k = 0; k < T && bad <= f->tol; k++)
+            if (gbit(f, (int64_t)i - (int64_t)sps * (T - 1 - k)) != f->trig[k]) bad++;
+        f->M[i] = (uint8_t)(bad <= f->tol);
     }
     /* run starts located in word w are examined when word w+1 has been processed */
     int64_t w_lo = (int64_t)(lo / AMPS_WORD_SAMPLES) - 1, w_hi = (int64_t)(hi / AMPS_WORD_SAMPLES) - 1;
