@@ -19,10 +19,11 @@
 //     64 address instructions per thread per frame);
 //   * the fold is one v_pk_fma per tap against 4P register-resident coefficients; which coefficient set a branch
 //     uses alternates with the frame parity, so the frame loop is unrolled by two parities (by eight, see below);
-//   * FFT-1024 = five radix-4 Stockham passes; pass 1 runs on the registers the fold just produced, passes
-//     2-4 exchange through two 8 KiB LDS buffers, pass 5 leaves bins {t, t+256, t+512, t+768} in registers --
-//     so a thread owns the same four channels in every frame.  Twiddles are per-thread constants, computed
-//     once (12 complex registers);
+//   * FFT-1024 = Stockham passes of radix 4, 16, 4, 4 over a BATCH of four frames: pass 1 runs on the registers the
+//     fold just produced, the radix-16 pass is done by one wave per frame entirely in registers (in place in LDS),
+//     the last pass leaves bins {t, t+256, t+512, t+768} in registers -- so a thread owns the same four channels in
+//     every frame.  Three workgroup barriers per four frames.  Twiddles of the radix-4 passes are per-thread
+//     constants (12 registers), those of the radix-16 pass a 512-byte LDS table;
 //   * eight frames of a thread's four bins are kept in registers and written as 64-byte runs into the
 //     channel-major output (dwordx4 stores), which recc_front_kernel then streams at full rate.
 // No MFMA: the contraction per channel is 8..16 taps deep and the FFT is a butterfly network.
@@ -32,6 +33,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 #include "amps_recc.h"
 
@@ -73,25 +75,55 @@ __device__ __forceinline__ cf2 cmul(cf2 a, cf2 b)
 }
 __device__ __forceinline__ cf2 mul_mi(cf2 a) { return (cf2){ a.y, -a.x }; }   // a * (-i)
 
-// Measured and rejected on MI355X (1 GiB of wideband per launch, kernel ms): baseline 1.24; XOR-swizzled exchange
+// History on MI355X (1 GiB of wideband per launch, fused kernel ms): LDS sample ring 1.49 -> register delay lines 1.26 ->
+// fused discriminator 1.02 -> packed complex multiply 0.90 -> lock-step 4-way discriminator 0.87 -> two-frame prefetch 0.83
+// -> four-frame batches with a radix-16 pass 0.69 -> per-batch branch-free input path 0.67.
+// Measured and rejected (kernel ms at the time): baseline 1.24; XOR-swizzled exchange
 // buffers 1.36 (33 % of LDS cycles are bank conflicts, but the kernel is latency- not LDS-bound and the index math
 // sits on the critical path); padded buffers 2.0 (LDS over 80 KiB -> one workgroup per CU, LDS-ring version);
 // 4-frame output groups + recomputed twiddle powers + __launch_bounds__(256,3) 3.9 (168 VGPRs -> spills).
 
-// One frame of the filter bank for the thread's four branches (residues t + 256*jb).  PAR = parity of the
-// absolute frame index m: the two samples the thread just loaded belong to branches {0,1} (m even) or {2,3}
-// (m odd), and the fold of branch jb uses the coefficient set jb ^ 2 when (m+1) is odd -- all register indices
-// are compile-time constants.
-template <int P, int PAR>
-__device__ __forceinline__ void chz_frame(cf2 (&line)[4][P], const float (&coef)[4][P], const cf2 (&tw)[4][3],
-                                          cf2 n0, cf2 n1, cf2 *bufA, cf2 *bufB, int t, cf2 (&y)[4])
+// ---- the frame pipeline: four frames per batch, FFT-1024 = radix 4 x 16 x 4 x 4 (Stockham) ----
+// A workgroup is four waves, and a 1024-point frame is 64 lanes x 16 points: with FOUR frames in flight the middle
+// of the FFT becomes one in-register radix-16 pass in which wave w owns frame w of the batch outright.  Per batch:
+//   fold + pass 1 (radix 4, registers -> A), all four frames            | barrier
+//   pass 2 (radix 16): wave w reads frame w of A entirely, writes it back in place   | barrier
+//   pass 3 (radix 4): A -> C, all four frames                           | barrier
+//   pass 4 (radix 4): C -> registers (bins t, t+256, t+512, t+768 of every frame)
+// = 3 barriers per 4 frames.  The first version ran five radix-4 passes per frame with 4 barriers EACH; with the
+// barriers compiled out that kernel ran 20 % faster (0.854 -> 0.687 ms), i.e. a fifth of the time was barrier skew.
+// Frame buffers are padded by one element per 16 (cpad) so that the radix-16 write-back (stride 16 elements between
+// lanes) does not land on four banks.
+constexpr int CHZ_BATCH = 4;
+constexpr int CHZ_FB = CHZ_M + CHZ_M / 16;                     // padded frame buffer, cf2 elements
+__host__ __device__ constexpr int cpad(int n) { return n + (n >> 4); }
+
+__device__ __forceinline__ void dft4(cf2 a0, cf2 a1, cf2 a2, cf2 a3, cf2 (&o)[4])
 {
-    // ---- delay lines: shift in the two new samples (branch PAR*2 and PAR*2+1)
+    const cf2 v0 = a0 + a2, v1 = a0 - a2, v2 = a1 + a3, v3 = mul_mi(a1 - a3);
+    o[0] = v0 + v2; o[1] = v1 + v3; o[2] = v0 - v2; o[3] = v1 - v3;
+}
+
+// e^{-2 pi i num / den}, argument reduced exactly (sincospif)
+__device__ __forceinline__ cf2 chz_twiddle(int num, int den)
+{
+    float sn, cs;
+    sincospif(-2.0f * (float)num / (float)den, &sn, &cs);
+    return (cf2){ cs, sn };
+}
+
+// One frame: shift the two new samples into the thread's delay lines, fold, radix-4 pass 1 -> A[4t .. 4t+3].
+// PAR = parity of the absolute frame index m: the two samples the thread just loaded belong to branches {0,1}
+// (m even) or {2,3} (m odd), and the fold of branch jb uses the coefficient set jb ^ 2 when (m+1) is odd -- all
+// register indices are compile-time constants.
+template <int P, int PAR>
+__device__ __forceinline__ void chz_fold_p1(cf2 (&line)[4][P], const float (&coef)[4][P], cf2 n0, cf2 n1, cf2 *A, int t)
+{
 #pragma unroll
     for (int q = 0; q + 1 < P; q++) { line[2 * PAR][q] = line[2 * PAR][q + 1]; line[2 * PAR + 1][q] = line[2 * PAR + 1][q + 1]; }
     line[2 * PAR][P - 1] = n0;
     line[2 * PAR + 1][P - 1] = n1;
-    // ---- fold: x[jb] = sum_q h[t + 256 j + qM] * line[jb][q],  j = jb ^ (2 * ((m+1) & 1))
+    // fold: x[jb] = sum_q h[t + 256 j + qM] * line[jb][q],  j = jb ^ (2 * ((m+1) & 1))
     constexpr int SW = 2 * ((PAR + 1) & 1);
     cf2 x[4];
 #pragma unroll
@@ -101,37 +133,133 @@ __device__ __forceinline__ void chz_frame(cf2 (&line)[4][P], const float (&coef)
         for (int q = 0; q < P; q++) s = __builtin_elementwise_fma(line[jb][q], (cf2){ coef[jb ^ SW][q], coef[jb ^ SW][q] }, s);
         x[jb] = s;
     }
-    // ---- FFT-1024, radix-4 Stockham.  pass 1 (Ns = 1): registers -> bufA[4t .. 4t+3]
-    {
-        cf2 v0 = x[0] + x[2], v1 = x[0] - x[2], v2 = x[1] + x[3], v3 = mul_mi(x[1] - x[3]);
-        bufA[4 * t + 0] = v0 + v2; bufA[4 * t + 1] = v1 + v3; bufA[4 * t + 2] = v0 - v2; bufA[4 * t + 3] = v1 - v3;
-    }
-    __syncthreads();
-    // passes 2..4 through LDS, pass 5 into registers (bins t, t+256, t+512, t+768)
+    cf2 o[4];
+    dft4(x[0], x[1], x[2], x[3], o);                            // radix 4, p = 1: no twiddles
+    cf2 *d = A + cpad(4 * t);                                   // 4t .. 4t+3 share one 16-group
+    d[0] = o[0]; d[1] = o[1]; d[2] = o[2]; d[3] = o[3];
+}
+
+// pass 2, radix 16, p = 4, one frame per wave, in place.  lane i: k = i & 3, u[r] = A[i + 64 r] e^{-2 pi i r k / 64},
+// X = DFT16(u), A[16 (i - k) + k + 4 r] = X[r].  tab[r][k] holds the twiddles (LDS, 512 B).
+__device__ __forceinline__ void chz_p2(cf2 *A, const cf2 *tab, int lane)
+{
+    const int k = lane & 3;
+    cf2 u[16];
+    const cf2 *src = A + cpad(lane);                            // cpad(lane + 64 r) = cpad(lane) + 68 r
 #pragma unroll
-    for (int p = 0; p < 4; p++) {
-        const int Ns = 4 << (2 * p);
-        const cf2 *src = (p & 1) ? bufB : bufA;
-        cf2 *dst = (p & 1) ? bufA : bufB;
-        cf2 a0 = src[t], a1 = cmul(src[t + 256], tw[p][0]), a2 = cmul(src[t + 512], tw[p][1]), a3 = cmul(src[t + 768], tw[p][2]);
-        cf2 v0 = a0 + a2, v1 = a0 - a2, v2 = a1 + a3, v3 = mul_mi(a1 - a3);
-        y[0] = v0 + v2; y[1] = v1 + v3; y[2] = v0 - v2; y[3] = v1 - v3;
-        if (p < 3) {
-            const int k = t & (Ns - 1);
-            const int i = ((t - k) << 2) + k;
-            dst[i] = y[0]; dst[i + Ns] = y[1]; dst[i + 2 * Ns] = y[2]; dst[i + 3 * Ns] = y[3];
-            __syncthreads();
-        }
+    for (int r = 0; r < 16; r++) u[r] = src[68 * r];
+    {
+        // The 15 twiddles are loop invariant; hoisted out of the batch loop they would pin 30 VGPRs the kernel does
+        // not have.  The empty asm hides the invariance of the index (laundering the POINTER instead turns the reads
+        // into flat loads); re-reading 120 B of LDS per batch is free.
+        int kk = k;
+        asm volatile("" : "+v"(kk));
+#pragma unroll
+        for (int r = 1; r < 16; r++) u[r] = cmul(u[r], tab[4 * r + kk]);
+    }
+    // DFT16 = 4 x DFT4 over a (s = 4a + b), twiddle W16^{bc}, 4 x DFT4 over b -> X[c + 4d]
+    cf2 v[4][4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) dft4(u[b], u[4 + b], u[8 + b], u[12 + b], v[b]);
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
+    v[1][1] = cmul(v[1][1], (cf2){ C1, -S1 });                  // W16^1
+    v[1][2] = cmul(v[1][2], (cf2){ R2, -R2 });                  // W16^2
+    v[1][3] = cmul(v[1][3], (cf2){ S1, -C1 });                  // W16^3
+    v[2][1] = cmul(v[2][1], (cf2){ R2, -R2 });                  // W16^2
+    v[2][2] = mul_mi(v[2][2]);                                  // W16^4 = -i
+    v[2][3] = cmul(v[2][3], (cf2){ -R2, -R2 });                 // W16^6
+    v[3][1] = cmul(v[3][1], (cf2){ S1, -C1 });                  // W16^3
+    v[3][2] = cmul(v[3][2], (cf2){ -R2, -R2 });                 // W16^6
+    v[3][3] = cmul(v[3][3], (cf2){ -C1, S1 });                  // W16^9
+    // all reads of this wave precede its writes in program order; nobody else touches this frame during pass 2
+    cf2 *dst = A + 17 * (lane - k) + k;                         // cpad(16 (i-k) + k + 4 r) = 17 (i-k) + k + 4 r + (r >> 2)
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        cf2 X[4];
+        dft4(v[0][c], v[1][c], v[2][c], v[3][c], X);
+#pragma unroll
+        for (int d = 0; d < 4; d++) dst[4 * (c + 4 * d) + d] = X[d];   // r = c + 4 d, (r >> 2) = d
     }
 }
+
+// pass 3, radix 4, p = 64: u[r] = B[t + 256 r] e^{-2 pi i r k / 256}, k = t & 63; C[4 (t - k) + k + 64 r] = X[r]
+__device__ __forceinline__ void chz_p3(const cf2 *A, cf2 *Cb, const cf2 (&tw)[3], int t)
+{
+    const cf2 *src = A + cpad(t);                               // cpad(t + 256 r) = cpad(t) + 272 r
+    cf2 o[4];
+    dft4(src[0], cmul(src[272], tw[0]), cmul(src[544], tw[1]), cmul(src[816], tw[2]), o);
+    const int k = t & 63;
+    cf2 *d = Cb + cpad(4 * (t - k) + k);                        // cpad(j + 64 r) = cpad(j) + 68 r
+    d[0] = o[0]; d[68] = o[1]; d[136] = o[2]; d[204] = o[3];
+}
+
+// pass 4, radix 4, p = 256: bins t + 256 r of the frame
+__device__ __forceinline__ void chz_p4(const cf2 *Cb, const cf2 (&tw)[3], int t, cf2 (&y)[4])
+{
+    const cf2 *src = Cb + cpad(t);
+    dft4(src[0], cmul(src[272], tw[0]), cmul(src[544], tw[1]), cmul(src[816], tw[2]), y);
+}
+
+// per-thread constants of the pipeline
+template <int P> struct ChzRegs {
+    float coef[4][P];        // h[t + 256 j + qM]
+    cf2 tw3[3], tw4[3];      // pass 3 / pass 4 twiddles
+};
+template <int P>
+__device__ __forceinline__ void chz_setup(ChzRegs<P> &R, const float *taps, cf2 *tab, int t)
+{
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int q = 0; q < P; q++) R.coef[j][q] = taps[t + 256 * j + q * CHZ_M];
+#pragma unroll
+    for (int r = 1; r < 4; r++) { R.tw3[r - 1] = chz_twiddle(r * (t & 63), 256); R.tw4[r - 1] = chz_twiddle(r * t, 1024); }
+    if (t < 64) tab[t] = chz_twiddle((t >> 2) * (t & 3), 64);   // tab[4 r + k]
+}
+
+// Input samples of launch-relative frame F for this thread: virtual indices F*D + t and F*D + 256 + t.  A batch that
+// lies inside the new block (all but the first and last of a launch) is plain coalesced loads; the generic path walks
+// carry / block / zero padding.  The choice is made once per batch, so the common path has no branch between the four
+// folds (per-frame branches cost 8 %: they fence the scheduler).
+struct ChzIn {
+    const float2 *block, *carry;
+    int64_t hist, lead, carry_len, nsamp;
+    __device__ __forceinline__ cf2 generic(int64_t v) const
+    {
+        const int64_t ci = v + hist;
+        if (ci < 0) return (cf2){ 0.f, 0.f };
+        float2 s;
+        if (ci < carry_len) s = carry[ci];
+        else { const int64_t bi = v - lead; if (bi >= nsamp) return (cf2){ 0.f, 0.f }; s = block[bi]; }
+        return (cf2){ s.x, s.y };
+    }
+    // all CHZ_BATCH frames starting at F lie inside the new block (wave-uniform)
+    __device__ __forceinline__ bool batch_in_block(int64_t F) const
+    {
+        const int64_t b0 = F * CHZ_D - lead;
+        return b0 >= 0 && b0 + CHZ_BATCH * CHZ_D <= nsamp;
+    }
+    template <bool FAST>
+    __device__ __forceinline__ void frame(int64_t F, int t, cf2 &s0, cf2 &s1) const
+    {
+        if constexpr (FAST) {
+            const float2 *p = block + (F * CHZ_D - lead) + t;
+            const float2 u = p[0], w = p[256];
+            s0 = (cf2){ u.x, u.y }; s1 = (cf2){ w.x, w.y };
+        } else {
+            s0 = generic(F * CHZ_D + t); s1 = generic(F * CHZ_D + 256 + t);
+        }
+    }
+};
 
 template <int P>
 __global__ __launch_bounds__(256) void chz_pfb_fft_kernel(ChzArgs a)
 {
     constexpr int M = CHZ_M, D = CHZ_D;
-    __shared__ cf2 bufA[CHZ_M];
-    __shared__ cf2 bufB[CHZ_M];
-    const int t = threadIdx.x;
+    __shared__ cf2 bufA[CHZ_BATCH * CHZ_FB];
+    __shared__ cf2 bufC[CHZ_BATCH * CHZ_FB];
+    __shared__ cf2 tab[64];
+    const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
     const uint32_t f0 = blockIdx.x * a.frames_per_wg;          // first frame of this workgroup (launch-relative, multiple of 8)
     if (f0 >= a.nframes) return;
     uint32_t f1 = f0 + a.frames_per_wg; if (f1 > a.nframes) f1 = a.nframes;
@@ -139,35 +267,9 @@ __global__ __launch_bounds__(256) void chz_pfb_fft_kernel(ChzArgs a)
     // virtual input stream of this launch: index v in [-(L-D), nsamp + leftover): carry then block.
     // frame f (launch-relative) consumes v in [f*D - (L-D), f*D + D); the absolute frame index of f = 0 is even
     // (the host only ever consumes an even number of frames), so parity(m) = parity(f) and residue(v) = v mod M.
-    const int64_t hist = (int64_t)a.hist;
-    const int64_t lead = (int64_t)a.carry_len - hist;          // leftover samples that precede the block
-    auto fetch = [&](int64_t v) -> cf2 {
-        int64_t ci = v + hist;                                  // index into carry
-        if (ci < 0) return (cf2){ 0.f, 0.f };
-        float2 s;
-        if (ci < (int64_t)a.carry_len) s = a.carry[ci];
-        else { int64_t bi = v - lead; if (bi >= (int64_t)a.nsamp) return (cf2){ 0.f, 0.f }; s = a.block[bi]; }
-        return (cf2){ s.x, s.y };
-    };
-
-    // coefficients h[t + 256 j + qM]
-    float coef[4][P];
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-#pragma unroll
-        for (int q = 0; q < P; q++) coef[j][q] = a.taps[t + 256 * j + q * M];
-    // twiddles of passes 2..5: w1 = exp(-2 pi i k / (4 Ns)), k = t & (Ns-1), Ns = 4, 16, 64, 256
-    cf2 tw[4][3];
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-        const int Ns = 4 << (2 * p);
-        const int k = t & (Ns - 1);
-        float sn, cs;
-        sincosf(-6.283185307179586f * (float)k / (float)(4 * Ns), &sn, &cs);
-        tw[p][0] = (cf2){ cs, sn };
-        tw[p][1] = cmul(tw[p][0], tw[p][0]);
-        tw[p][2] = cmul(tw[p][1], tw[p][0]);
-    }
+    const ChzIn in{ a.block, a.carry, (int64_t)a.hist, (int64_t)a.carry_len - (int64_t)a.hist, (int64_t)a.carry_len, (int64_t)a.nsamp };
+    ChzRegs<P> R;
+    chz_setup<P>(R, a.taps, tab, t);
     // delay lines: branch jb (residue r = t + 256 jb) holds its P most recent samples before frame f0:
     // v_last = largest v < f0*D with v mod M == r   (f0*D is a multiple of M because f0 is even)
     cf2 line[4][P];
@@ -177,24 +279,36 @@ __global__ __launch_bounds__(256) void chz_pfb_fft_kernel(ChzArgs a)
         for (int jb = 0; jb < 4; jb++) {
             const int64_t vlast = vend - M + (t + 256 * jb);
 #pragma unroll
-            for (int q = 0; q < P; q++) line[jb][q] = fetch(vlast - (int64_t)M * (P - 1 - q));
+            for (int q = 0; q < P; q++) line[jb][q] = in.generic(vlast - (int64_t)M * (P - 1 - q));
         }
     }
+    __syncthreads();                                             // tab
 
-    // eight frames of this thread's four bins stay in registers and leave as 64-byte runs of the channel-major output
-    cf2 nx0 = fetch((int64_t)f0 * D + t), nx1 = fetch((int64_t)f0 * D + 256 + t);
+    // eight frames (two batches) of this thread's four bins stay in registers and leave as 64-byte runs of the
+    // channel-major output.  Frames past f1 (a partial last group) run on zero padding and are not stored.
     for (uint32_t fg = f0; fg < f1; fg += CHZ_GROUP) {
         cf2 acc[CHZ_GROUP][4];
         const int ng = (int)(f1 - fg < (uint32_t)CHZ_GROUP ? f1 - fg : (uint32_t)CHZ_GROUP);
 #pragma unroll
-        for (int g = 0; g < CHZ_GROUP; g++) {
-            if (g < ng) {
-                const cf2 c0 = nx0, c1 = nx1;
-                const int64_t vn = (int64_t)(fg + g + 1) * D;             // next frame's samples (zero beyond the data)
-                nx0 = fetch(vn + t); nx1 = fetch(vn + 256 + t);
-                if (g & 1) chz_frame<P, 1>(line, coef, tw, c0, c1, bufA, bufB, t, acc[g]);
-                else chz_frame<P, 0>(line, coef, tw, c0, c1, bufA, bufB, t, acc[g]);
-            }
+        for (int hb = 0; hb < CHZ_GROUP; hb += CHZ_BATCH) {
+            auto fold4 = [&](auto fastc) {
+#pragma unroll
+                for (int g = 0; g < CHZ_BATCH; g++) {
+                    cf2 c0, c1;
+                    in.template frame<decltype(fastc)::value>((int64_t)fg + hb + g, t, c0, c1);
+                    if (g & 1) chz_fold_p1<P, 1>(line, R.coef, c0, c1, bufA + g * CHZ_FB, t);
+                    else chz_fold_p1<P, 0>(line, R.coef, c0, c1, bufA + g * CHZ_FB, t);
+                }
+            };
+            if (in.batch_in_block((int64_t)fg + hb)) fold4(std::true_type{}); else fold4(std::false_type{});
+            __syncthreads();
+            chz_p2(bufA + wv * CHZ_FB, tab, lane);
+            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < CHZ_BATCH; g++) chz_p3(bufA + g * CHZ_FB, bufC + g * CHZ_FB, R.tw3, t);
+            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < CHZ_BATCH; g++) chz_p4(bufC + g * CHZ_FB, R.tw4, t, acc[hb + g]);
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -237,45 +351,24 @@ __device__ __forceinline__ void chz_bins(const cf2 (&y)[4], cf2 (&prev)[4], floa
     }
 }
 
-// 226 VGPRs -> two waves per SIMD; __launch_bounds__(256, 3) forces 168 and spills 212 B/lane (2.9 ms instead of 1.0)
+// P = 8 is held to 256 VGPRs = two waves per SIMD (left alone the allocator takes 258 and halves the occupancy;
+// __launch_bounds__(256, 3) would force 168 and spill: 2.9 ms instead of 1.0).  P = 16 needs ~390: one wave per SIMD.
 template <int P>
-__global__ __launch_bounds__(256) void chz_fused_kernel(ChzArgs a)
+__global__ __launch_bounds__(256, P <= 8 ? 2 : 1) void chz_fused_kernel(ChzArgs a)
 {
     constexpr int M = CHZ_M, D = CHZ_D;
-    __shared__ cf2 bufA[CHZ_M];
-    __shared__ cf2 bufB[CHZ_M];
-    const int t = threadIdx.x;
+    __shared__ cf2 bufA[CHZ_BATCH * CHZ_FB];
+    __shared__ cf2 bufC[CHZ_BATCH * CHZ_FB];
+    __shared__ cf2 tab[64];
+    const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
     const int64_t f0 = (int64_t)blockIdx.x * a.frames_per_wg;   // multiple of 64
     if (f0 >= (int64_t)a.nframes) return;
     int64_t f1 = f0 + a.frames_per_wg; if (f1 > (int64_t)a.nframes) f1 = a.nframes;
-    const int64_t fs = f0 - CHZ_PRE;                             // pre-roll: rebuild prev / d1 / d2 of every bin
+    const int64_t fs = f0 - CHZ_PRE;                             // pre-roll (one batch): rebuild prev / d1 / d2 of every bin
 
-    const int64_t hist = (int64_t)a.hist;
-    const int64_t lead = (int64_t)a.carry_len - hist;
-    auto fetch = [&](int64_t v) -> cf2 {
-        int64_t ci = v + hist;
-        if (ci < 0) return (cf2){ 0.f, 0.f };
-        float2 s;
-        if (ci < (int64_t)a.carry_len) s = a.carry[ci];
-        else { int64_t bi = v - lead; if (bi >= (int64_t)a.nsamp) return (cf2){ 0.f, 0.f }; s = a.block[bi]; }
-        return (cf2){ s.x, s.y };
-    };
-    float coef[4][P];
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-#pragma unroll
-        for (int q = 0; q < P; q++) coef[j][q] = a.taps[t + 256 * j + q * M];
-    cf2 tw[4][3];
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-        const int Ns = 4 << (2 * p);
-        const int k = t & (Ns - 1);
-        float sn, cs;
-        sincosf(-6.283185307179586f * (float)k / (float)(4 * Ns), &sn, &cs);
-        tw[p][0] = (cf2){ cs, sn };
-        tw[p][1] = cmul(tw[p][0], tw[p][0]);
-        tw[p][2] = cmul(tw[p][1], tw[p][0]);
-    }
+    const ChzIn in{ a.block, a.carry, (int64_t)a.hist, (int64_t)a.carry_len - (int64_t)a.hist, (int64_t)a.carry_len, (int64_t)a.nsamp };
+    ChzRegs<P> R;
+    chz_setup<P>(R, a.taps, tab, t);
     cf2 line[4][P];
     {
         const int64_t vend = fs * D;                              // multiple of M (fs is even)
@@ -283,7 +376,7 @@ __global__ __launch_bounds__(256) void chz_fused_kernel(ChzArgs a)
         for (int jb = 0; jb < 4; jb++) {
             const int64_t vlast = vend - M + (t + 256 * jb);
 #pragma unroll
-            for (int q = 0; q < P; q++) line[jb][q] = fetch(vlast - (int64_t)M * (P - 1 - q));
+            for (int q = 0; q < P; q++) line[jb][q] = in.generic(vlast - (int64_t)M * (P - 1 - q));
         }
     }
     cf2 prev[4] = {};
@@ -291,28 +384,36 @@ __global__ __launch_bounds__(256) void chz_fused_kernel(ChzArgs a)
     uint32_t gw[4] = { ~0u, ~0u, ~0u, ~0u };
     const uint64_t mask32 = 2ull * a.ring_words - 1;
 
-    // input prefetch two frames ahead (one frame is ~1.8 us of work, about one loaded-HBM latency): 0.869 -> 0.833 ms.
-    // (P = 16 runs at one wave per SIMD, 378 VGPRs, so the extra registers are free there too.)
-    constexpr bool DEEP = true;
-    cf2 na0 = fetch(fs * D + t), na1 = fetch(fs * D + 256 + t);
-    cf2 nb0 = na0, nb1 = na1;
-    if constexpr (DEEP) { nb0 = fetch((fs + 1) * D + t); nb1 = fetch((fs + 1) * D + 256 + t); }
-    for (int64_t f = fs; f < f1; f += 2) {
-        cf2 y[4];
+    // the inputs of a whole batch are loaded one batch (~7 us) ahead
+    cf2 nx[CHZ_BATCH][2];
 #pragma unroll
-        for (int par = 0; par < 2; par++) {
-            const cf2 c0 = na0, c1 = na1;
-            if constexpr (DEEP) {
-                na0 = nb0; na1 = nb1;
-                nb0 = fetch((f + par + 2) * D + t); nb1 = fetch((f + par + 2) * D + 256 + t);
-            } else {
-                na0 = fetch((f + par + 1) * D + t); na1 = fetch((f + par + 1) * D + 256 + t);
+    for (int g = 0; g < CHZ_BATCH; g++) in.template frame<false>(fs + g, t, nx[g][0], nx[g][1]);
+    __syncthreads();                                             // tab
+
+    for (int64_t f = fs; f < f1; f += CHZ_BATCH) {               // fs and f1 are multiples of 4
+        auto fold4 = [&](auto fastc) {                           // fold this batch, load the next one behind each fold
+#pragma unroll
+            for (int g = 0; g < CHZ_BATCH; g++) {
+                if (g & 1) chz_fold_p1<P, 1>(line, R.coef, nx[g][0], nx[g][1], bufA + g * CHZ_FB, t);
+                else chz_fold_p1<P, 0>(line, R.coef, nx[g][0], nx[g][1], bufA + g * CHZ_FB, t);
+                in.template frame<decltype(fastc)::value>(f + CHZ_BATCH + g, t, nx[g][0], nx[g][1]);   // generic: zero beyond the data
             }
-            if (par == 0) { chz_frame<P, 0>(line, coef, tw, c0, c1, bufA, bufB, t, y); chz_bins<0, DEEP>(y, prev, d1, d2, gw); }
-            else { chz_frame<P, 1>(line, coef, tw, c0, c1, bufA, bufB, t, y); chz_bins<1, DEEP>(y, prev, d1, d2, gw); }
+        };
+        if (in.batch_in_block(f + CHZ_BATCH)) fold4(std::true_type{}); else fold4(std::false_type{});
+        __syncthreads();
+        chz_p2(bufA + wv * CHZ_FB, tab, lane);
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < CHZ_BATCH; g++) chz_p3(bufA + g * CHZ_FB, bufC + g * CHZ_FB, R.tw3, t);
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < CHZ_BATCH; g++) {
+            cf2 y[4];
+            chz_p4(bufC + g * CHZ_FB, R.tw4, t, y);
+            if (g & 1) chz_bins<1>(y, prev, d1, d2, gw); else chz_bins<0>(y, prev, d1, d2, gw);
         }
-        if (f >= f0 && ((f + 1) & 31) == 31) {                    // 32 real frames collected (f0 is a multiple of 64)
-            const uint64_t n = a.n_done + (uint64_t)(f + 1);      // absolute index of the newest bit
+        if (f >= f0 && ((f + 3) & 31) == 31) {                    // 32 real frames collected (f0 is a multiple of 64)
+            const uint64_t n = a.n_done + (uint64_t)(f + 3);      // absolute index of the newest bit
 #pragma unroll
             for (int j = 0; j < 4; j++) {                         // channel / ring address recomputed here: 12 fewer live VGPRs
                 const uint32_t ch = ((uint32_t)(t + 256 * j) - a.first_bin) & (M - 1);
