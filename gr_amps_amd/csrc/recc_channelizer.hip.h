@@ -112,31 +112,52 @@ __device__ __forceinline__ cf2 chz_twiddle(int num, int den)
     return (cf2){ cs, sn };
 }
 
-// One frame: shift the two new samples into the thread's delay lines, fold, radix-4 pass 1 -> A[4t .. 4t+3].
-// PAR = parity of the absolute frame index m: the two samples the thread just loaded belong to branches {0,1}
-// (m even) or {2,3} (m odd), and the fold of branch jb uses the coefficient set jb ^ 2 when (m+1) is odd -- all
-// register indices are compile-time constants.
-template <int P, int PAR>
-__device__ __forceinline__ void chz_fold_p1(cf2 (&line)[4][P], const float (&coef)[4][P], cf2 n0, cf2 n1, cf2 *A, int t)
+// One frame: fold x[jb] = sum_q h[t + 256 j + qM] * win[jb][q], j = jb ^ (2 * ((m+1) & 1)), then the radix-4 pass 1 ->
+// A[4t .. 4t+3].  The tap window of branch jb is ext[jb][S .. S+P): ext = {delay line, the batch's new samples} and S (SA for
+// branches 0,1; SB for 2,3) counts the samples of this batch already shifted in.  PAR = parity of the absolute frame index
+// m: which coefficient set a branch uses alternates with it.  All register indices are compile-time constants.
+template <int P, int PAR, int SA, int SB>
+__device__ __forceinline__ void chz_fold_p1(const cf2 (&ext)[4][P + 2], const float (&coef)[4][P], cf2 *A, int t)
 {
-#pragma unroll
-    for (int q = 0; q + 1 < P; q++) { line[2 * PAR][q] = line[2 * PAR][q + 1]; line[2 * PAR + 1][q] = line[2 * PAR + 1][q + 1]; }
-    line[2 * PAR][P - 1] = n0;
-    line[2 * PAR + 1][P - 1] = n1;
-    // fold: x[jb] = sum_q h[t + 256 j + qM] * line[jb][q],  j = jb ^ (2 * ((m+1) & 1))
     constexpr int SW = 2 * ((PAR + 1) & 1);
     cf2 x[4];
 #pragma unroll
     for (int jb = 0; jb < 4; jb++) {
+        const int sh = jb < 2 ? SA : SB;
         cf2 s = { 0.f, 0.f };
 #pragma unroll
-        for (int q = 0; q < P; q++) s = __builtin_elementwise_fma(line[jb][q], (cf2){ coef[jb ^ SW][q], coef[jb ^ SW][q] }, s);
+        for (int q = 0; q < P; q++) s = __builtin_elementwise_fma(ext[jb][sh + q], (cf2){ coef[jb ^ SW][q], coef[jb ^ SW][q] }, s);
         x[jb] = s;
     }
     cf2 o[4];
     dft4(x[0], x[1], x[2], x[3], o);                            // radix 4, p = 1: no twiddles
     cf2 *d = A + cpad(4 * t);                                   // 4t .. 4t+3 share one 16-group
     d[0] = o[0]; d[1] = o[1]; d[2] = o[2]; d[3] = o[3];
+}
+
+// The four frames of a batch.  Frame g brings two new samples per thread, for branches {0,1} (g even) or {2,3} (g odd).
+// The four tap windows are views of {delay line, new samples} at compile-time offsets, so within the batch nothing moves;
+// the delay lines are shifted once per batch, by two samples per branch (shifting per frame cost 150 v_mov per batch,
+// a tenth of the instruction stream).
+template <int P>
+__device__ __forceinline__ void chz_fold_batch(cf2 (&line)[4][P], const float (&coef)[4][P], const cf2 (&nx)[CHZ_BATCH][2], cf2 *bufA, int t)
+{
+    cf2 ext[4][P + 2];
+#pragma unroll
+    for (int jb = 0; jb < 4; jb++) {
+#pragma unroll
+        for (int q = 0; q < P; q++) ext[jb][q] = line[jb][q];
+        ext[jb][P] = nx[jb >> 1][jb & 1];                       // frames 0 / 1 feed branches {0,1} / {2,3}
+        ext[jb][P + 1] = nx[2 + (jb >> 1)][jb & 1];             // frames 2 / 3
+    }
+    chz_fold_p1<P, 0, 1, 0>(ext, coef, bufA, t);
+    chz_fold_p1<P, 1, 1, 1>(ext, coef, bufA + CHZ_FB, t);
+    chz_fold_p1<P, 0, 2, 1>(ext, coef, bufA + 2 * CHZ_FB, t);
+    chz_fold_p1<P, 1, 2, 2>(ext, coef, bufA + 3 * CHZ_FB, t);
+#pragma unroll
+    for (int jb = 0; jb < 4; jb++)
+#pragma unroll
+        for (int q = 0; q < P; q++) line[jb][q] = ext[jb][q + 2];
 }
 
 // pass 2, radix 16, p = 4, one frame per wave, in place.  lane i: k = i & 3, u[r] = A[i + 64 r] e^{-2 pi i r k / 64},
@@ -292,13 +313,10 @@ __global__ __launch_bounds__(256) void chz_pfb_fft_kernel(ChzArgs a)
 #pragma unroll
         for (int hb = 0; hb < CHZ_GROUP; hb += CHZ_BATCH) {
             auto fold4 = [&](auto fastc) {
+                cf2 nx[CHZ_BATCH][2];
 #pragma unroll
-                for (int g = 0; g < CHZ_BATCH; g++) {
-                    cf2 c0, c1;
-                    in.template frame<decltype(fastc)::value>((int64_t)fg + hb + g, t, c0, c1);
-                    if (g & 1) chz_fold_p1<P, 1>(line, R.coef, c0, c1, bufA + g * CHZ_FB, t);
-                    else chz_fold_p1<P, 0>(line, R.coef, c0, c1, bufA + g * CHZ_FB, t);
-                }
+                for (int g = 0; g < CHZ_BATCH; g++) in.template frame<decltype(fastc)::value>((int64_t)fg + hb + g, t, nx[g][0], nx[g][1]);
+                chz_fold_batch<P>(line, R.coef, nx, bufA, t);
             };
             if (in.batch_in_block((int64_t)fg + hb)) fold4(std::true_type{}); else fold4(std::false_type{});
             __syncthreads();
@@ -391,13 +409,11 @@ __global__ __launch_bounds__(256, P <= 8 ? 2 : 1) void chz_fused_kernel(ChzArgs 
     __syncthreads();                                             // tab
 
     for (int64_t f = fs; f < f1; f += CHZ_BATCH) {               // fs and f1 are multiples of 4
-        auto fold4 = [&](auto fastc) {                           // fold this batch, load the next one behind each fold
+        auto fold4 = [&](auto fastc) {                           // fold this batch, then load the next one (a batch ahead)
+            chz_fold_batch<P>(line, R.coef, nx, bufA, t);
 #pragma unroll
-            for (int g = 0; g < CHZ_BATCH; g++) {
-                if (g & 1) chz_fold_p1<P, 1>(line, R.coef, nx[g][0], nx[g][1], bufA + g * CHZ_FB, t);
-                else chz_fold_p1<P, 0>(line, R.coef, nx[g][0], nx[g][1], bufA + g * CHZ_FB, t);
+            for (int g = 0; g < CHZ_BATCH; g++)
                 in.template frame<decltype(fastc)::value>(f + CHZ_BATCH + g, t, nx[g][0], nx[g][1]);   // generic: zero beyond the data
-            }
         };
         if (in.batch_in_block(f + CHZ_BATCH)) fold4(std::true_type{}); else fold4(std::false_type{});
         __syncthreads();
