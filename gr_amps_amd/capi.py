@@ -81,7 +81,7 @@ EXPORTS = (
     "amps_recc_push_iq", "amps_recc_push_wideband", "amps_recc_drain", "amps_recc_debug_demod",
     "amps_recc_get_timing", "amps_recc_reply_words", "amps_recc_debug_channelize",
     "amps_bch_encode_words", "amps_bch_decode_words",
-    "amps_recc_set_xlate", "amps_recc_push_raw", "amps_recc_debug_xlate",
+    "amps_recc_set_xlate", "amps_recc_push_raw", "amps_recc_debug_xlate", "amps_recc_set_timing",
 )
 
 _lib = None
@@ -119,6 +119,7 @@ def load():
     L.amps_recc_drain.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.amps_recc_debug_demod.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, vp, vp]
     L.amps_recc_get_timing.argtypes = [vp, C.POINTER(Timing), C.c_int]
+    L.amps_recc_set_timing.argtypes = [vp, C.c_int]
     L.amps_recc_debug_channelize.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.amps_recc_reply_words.argtypes = [vp, C.POINTER(Reply)]
     L.amps_recc_set_xlate.argtypes = [vp, C.POINTER(XlateCfg)]
@@ -346,6 +347,12 @@ class Recc:
             raise AmpsError(rc, "amps_recc_debug_demod")
         p = (n // 64) * 64
         return d[:p], s[:p], g[:p]
+
+    def set_timing(self, mode):
+        """mode: "off" | "all" | "dominant" (only the streaming kernel of the seam in use is bracketed by HIP events)"""
+        rc = load().amps_recc_set_timing(self._h, {"off": 0, "all": 1, "dominant": 2}[mode])
+        if rc:
+            raise AmpsError(rc, "amps_recc_set_timing")
 
     def timing(self, reset=False):
         t = Timing()

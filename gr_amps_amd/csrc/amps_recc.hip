@@ -90,6 +90,8 @@ struct amps_recc {
 
     // ---- timing ----
     bool timing = false;
+    int timing_mode = 0;              // AMPS_RECC_TIMING_*
+    std::vector<hipEvent_t> event_pool;   // recycled by collect_spans
     std::vector<TimedSpan> spans;
     double ms[T_COUNT] = { 0 };
     uint32_t launches_front = 0, launches_chz = 0;
@@ -111,10 +113,20 @@ template <typename T> int dev_alloc(T **p, size_t n)
 
 struct SpanGuard {   // records a pair of events around a launch when timing is on
     amps_recc *h; int tag; uint64_t samples; hipEvent_t a = nullptr, b = nullptr; bool on;
+    static hipEvent_t take(amps_recc *h)
+    {
+        if (!h->event_pool.empty()) { hipEvent_t e = h->event_pool.back(); h->event_pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+    }
     SpanGuard(amps_recc *h_, int tag_, uint64_t samples_ = 0) : h(h_), tag(tag_), samples(samples_), on(h_->timing)
     {
+        // "dominant" mode: only the streaming kernel of the seam (front kernel, or the channelizer on the wideband
+        // seam) is bracketed -- two event records per push instead of ten, for timed regions that should not be perturbed
+        if (on && h->timing_mode == AMPS_RECC_TIMING_DOMINANT) on = (tag == T_CHANNELIZER) || (tag == T_FRONT && !h->chz.enabled);
         if (!on) return;
-        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+        a = take(h); b = take(h);
+        if (!a || !b) { on = false; return; }
         (void)hipEventRecord(a, h->stream);
     }
     ~SpanGuard()
@@ -134,8 +146,8 @@ void collect_spans(amps_recc *h)   // stream must be synchronised
             if (s.tag == T_FRONT) { h->launches_front++; h->samples_front += s.samples; }
             if (s.tag == T_CHANNELIZER) h->launches_chz++;
         }
-        (void)hipEventDestroy(s.a);
-        (void)hipEventDestroy(s.b);
+        h->event_pool.push_back(s.a);
+        h->event_pool.push_back(s.b);
     }
     h->spans.clear();
 }
@@ -372,6 +384,7 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
     h->C = cfg->n_channels;
     h->sps = cfg->samples_per_symbol;
     h->timing = (cfg->flags & AMPS_RECC_FLAG_TIME_KERNELS) != 0;
+    h->timing_mode = h->timing ? AMPS_RECC_TIMING_ALL : AMPS_RECC_TIMING_OFF;
     if (cfg->stream) h->stream = (hipStream_t)cfg->stream;
     else {
         if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return -EIO; }
@@ -430,6 +443,8 @@ void amps_recc_destroy(amps_recc_t *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     collect_spans(h);
+    for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
+    h->event_pool.clear();
     void *bufs[] = { h->carry[0], h->carry[1], h->gring, h->det, h->detcount, h->next_allowed, h->pending, h->capq,
                      h->capq_count, h->nrecords, h->status, h->stage_iq, h->symbuf, h->sym_len, h->sym_cur,
                      h->sym_stage, h->bursts_dev, h->burst_chan_dev, h->nbursts_dev, h->dec_out_dev, h->dec_in_dev,
@@ -790,6 +805,17 @@ int amps_recc_debug_channelize(amps_recc_t *h, const float *iq, size_t nsamp, in
         HIP_TRY(hipMemcpy2DAsync(out, out_ld * sizeof(float2), chan_iq, ld * sizeof(float2), nout * sizeof(float2), h->C,
                                  hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int amps_recc_set_timing(amps_recc_t *h, int mode)
+{
+    if (!h || mode < AMPS_RECC_TIMING_OFF || mode > AMPS_RECC_TIMING_DOMINANT) return -EINVAL;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    collect_spans(h);
+    h->timing_mode = mode;
+    h->timing = mode != AMPS_RECC_TIMING_OFF;
     return 0;
 }
 

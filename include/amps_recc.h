@@ -227,6 +227,13 @@ int amps_recc_debug_channelize(amps_recc_t *h, const float *iq, size_t nsamp, in
                                float *out, size_t out_ld, size_t *nframes);
 
 int amps_recc_get_timing(amps_recc_t *h, amps_recc_timing_t *t, int reset);
+/* HIP-event timing of the launches: OFF, ALL kernels (what AMPS_RECC_FLAG_TIME_KERNELS selects at creation), or only the
+ * DOMINANT streaming kernel of the seam in use (front kernel; channelizer on the wideband seam) -- two event records
+ * per push instead of ten, for timed regions that should not be perturbed.  Synchronises the stream. */
+#define AMPS_RECC_TIMING_OFF      0
+#define AMPS_RECC_TIMING_ALL      1
+#define AMPS_RECC_TIMING_DOMINANT 2
+int amps_recc_set_timing(amps_recc_t *h, int mode);
 
 /* reply generation of recc_decode: fills the focc_words / fvc_words payloads the
  * reference would publish for this burst.  Pure host integer code. */
