@@ -9,8 +9,8 @@
 //
 // Design notes (MI355X): a burst is 3374 symbol bytes -> 1687 bits -> 35 BCH blocks.  One wave
 // handles one burst: the 64 lanes stride over the symbol pairs (Manchester), lanes 0..34 each
-// decode one 48-bit block algebraically (syndromes S1,S3 in GF(64) from a 63-entry constant table,
-// closed-form locator for t=2, 63-step root count), lanes 0..6 pick the first valid repeat, and
+// decode one 48-bit block algebraically (syndromes S1,S3 in GF(64) as parities of constant masks,
+// closed-form locator for t=2, 63-step incremental root search, no tables), lanes 0..6 pick the first valid repeat, and
 // the record is written back cooperatively.  Everything stays in LDS (3.4 KB symbols + 1.7 KB
 // bits); bursts are rare events (<= 1 per 34 480 samples per channel), so this kernel is latency-
 // not bandwidth-critical and is kept simple.
@@ -22,6 +22,9 @@
 namespace amps {
 
 // ---- GF(64), primitive polynomial x^6 + x + 1 (the field IT++ uses for q = 64) ----
+// Table-free on the device: a first version looked alpha^e / log up in a __constant__ table with per-lane indices
+// (vector loads from constant memory inside divergent loops) and one burst took 51 us of pure latency; shift-and-xor
+// arithmetic in registers plus parity-of-mask syndromes needs no memory at all.
 struct Gf64Tables {
     uint8_t exp[128];
     uint8_t log[64];
@@ -42,16 +45,40 @@ constexpr Gf64Tables make_gf64()
     t.log[0] = 0;
     return t;
 }
-__constant__ Gf64Tables c_gf = make_gf64();
+// syndrome masks: bit k of S_m = parity(w & mask[m][k]) where w holds the received polynomial (bit e = coefficient of
+// x^e) and mask[m][k] collects the exponents e whose alpha^(m e) has bit k set   (m = 1, 3)
+struct SynMasks { uint64_t m1[6], m3[6]; };
+constexpr SynMasks make_syn_masks()
+{
+    SynMasks s{};
+    const Gf64Tables t = make_gf64();
+    for (int e = 0; e < 63; e++)
+        for (int k = 0; k < 6; k++) {
+            if ((t.exp[e] >> k) & 1) s.m1[k] |= 1ull << e;
+            if ((t.exp[(3 * e) % 63] >> k) & 1) s.m3[k] |= 1ull << e;
+        }
+    return s;
+}
+static constexpr SynMasks k_syn = make_syn_masks();
 
+__device__ __forceinline__ unsigned gf_xtime(unsigned a)      // a * alpha
+{
+    a <<= 1;
+    return a ^ ((a & 0x40u) ? 0x43u : 0u);
+}
 __device__ __forceinline__ unsigned gf_mul(unsigned a, unsigned b)
 {
-    return (a && b) ? c_gf.exp[c_gf.log[a] + c_gf.log[b]] : 0u;
+    unsigned r = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) { r ^= ((b >> i) & 1u) ? a : 0u; a = gf_xtime(a); }
+    return r;
 }
-__device__ __forceinline__ unsigned gf_div(unsigned a, unsigned b) // b != 0
+__device__ __forceinline__ unsigned gf_inv(unsigned a)        // a^62, a != 0
 {
-    return a ? c_gf.exp[c_gf.log[a] + 63 - c_gf.log[b]] : 0u;
+    const unsigned a2 = gf_mul(a, a), a4 = gf_mul(a2, a2), a8 = gf_mul(a4, a4), a16 = gf_mul(a8, a8), a32 = gf_mul(a16, a16);
+    return gf_mul(gf_mul(gf_mul(a2, a4), gf_mul(a8, a16)), a32);
 }
+__device__ __forceinline__ unsigned gf_div(unsigned a, unsigned b) { return gf_mul(a, gf_inv(b)); }   // b != 0
 
 // Result of decoding one 48-bit block: ok + up to 3 error exponents (coefficient of x^e flips).
 struct BchResult {
@@ -60,35 +87,39 @@ struct BchResult {
     int e[3];
 };
 
-// bits: nbits bytes (0/1), bit i is the coefficient of x^(nbits-1-i); the shortening zeros sit above x^(nbits-1).
+// w: received polynomial, bit e = coefficient of x^e (the shortening zeros are the bits above the block length).
 // Semantics = IT++ BCH(63,2,true)::decode: syndromes, two Berlekamp steps (closed form for t = 2),
-// root search over all 63 positions, failure iff #roots != deg(Lambda).  Roots in the 15 padding
-// positions are NOT rejected (the reference does not check them).
-__device__ inline BchResult bch_short_decode(const uint8_t *bits, int nbits)
+// root search over all 63 positions (in the order j = 0..62, root alpha^j <-> exponent (63 - j) % 63), failure iff
+// #roots != deg(Lambda).  Roots in the 15 padding positions are NOT rejected (the reference does not check them,
+// SURVEY.md 8a R4).
+__device__ inline BchResult bch63_decode_packed(uint64_t w)
 {
     BchResult r;
     r.ok = 0; r.nflip = 0; r.e[0] = r.e[1] = r.e[2] = -1;
     unsigned S1 = 0, S3 = 0;
-    for (int i = 0; i < nbits; i++) {
-        if (bits[i] & 1u) {
-            int e = nbits - 1 - i;
-            S1 ^= c_gf.exp[e];
-            S3 ^= c_gf.exp[(3 * e) % 63];
-        }
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        S1 |= (unsigned)(__popcll(w & k_syn.m1[k]) & 1) << k;
+        S3 |= (unsigned)(__popcll(w & k_syn.m3[k]) & 1) << k;
     }
     if ((S1 | S3) == 0) { r.ok = 1; return r; }
     if (S1 != 0) {
-        unsigned S1cube = gf_mul(gf_mul(S1, S1), S1);
-        unsigned delta = S3 ^ S1cube;            // Omega[3] = S3 + S1*S2, S2 = S1^2
+        const unsigned S1cube = gf_mul(gf_mul(S1, S1), S1);
+        const unsigned delta = S3 ^ S1cube;      // Omega[3] = S3 + S1*S2, S2 = S1^2
         if (delta == 0) {                        // Lambda = 1 + S1 x : single error at log(S1)
-            r.ok = 1; r.nflip = 1; r.e[0] = c_gf.log[S1];
+            unsigned p = 1;
+            int lg = 0;
+            for (int j = 0; j < 63; j++) { if (p == S1) lg = j; p = gf_xtime(p); }
+            r.ok = 1; r.nflip = 1; r.e[0] = lg;
             return r;
         }
-        unsigned c2 = gf_div(delta, S1);         // Lambda = 1 + S1 x + (delta/S1) x^2
+        const unsigned c2 = gf_div(delta, S1);   // Lambda = 1 + S1 x + (delta/S1) x^2
         int found = 0;
+        unsigned a = S1, b = c2;                 // S1 alpha^j, c2 alpha^(2j)
         for (int j = 0; j < 63; j++) {
-            unsigned v = 1u ^ gf_mul(S1, c_gf.exp[j]) ^ gf_mul(c2, c_gf.exp[(2 * j) % 63]);
-            if (v == 0 && found < 3) r.e[found++] = (63 - j) % 63;
+            if ((1u ^ a ^ b) == 0 && found < 3) r.e[found++] = (63 - j) % 63;
+            a = gf_xtime(a);
+            b = gf_xtime(gf_xtime(b));
         }
         if (found == 2) { r.ok = 1; r.nflip = 2; }
         return r;
@@ -96,13 +127,22 @@ __device__ inline BchResult bch_short_decode(const uint8_t *bits, int nbits)
     // S1 == 0, S3 != 0: first step leaves Lambda = 1 and T = x^2, second gives Lambda = 1 + S3 x^3
     {
         int found = 0;
+        unsigned c = S3;                         // S3 alpha^(3j)
         for (int j = 0; j < 63; j++) {
-            unsigned v = 1u ^ gf_mul(S3, c_gf.exp[(3 * j) % 63]);
-            if (v == 0 && found < 3) r.e[found++] = (63 - j) % 63;
+            if ((1u ^ c) == 0 && found < 3) r.e[found++] = (63 - j) % 63;
+            c = gf_xtime(gf_xtime(gf_xtime(c)));
         }
         if (found == 3) { r.ok = 1; r.nflip = 3; }
     }
     return r;
+}
+
+// bits: nbits bytes (0/1), bit i is the coefficient of x^(nbits-1-i); the shortening zeros sit above x^(nbits-1).
+__device__ inline BchResult bch_short_decode(const uint8_t *bits, int nbits)
+{
+    uint64_t w = 0;
+    for (int i = 0; i < nbits; i++) w |= (uint64_t)(bits[i] & 1u) << (nbits - 1 - i);
+    return bch63_decode_packed(w);
 }
 
 __device__ inline BchResult bch4836_decode(const uint8_t *bits) { return bch_short_decode(bits, 48); }

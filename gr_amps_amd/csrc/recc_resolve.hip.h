@@ -149,6 +149,10 @@ __global__ __launch_bounds__(64) void recc_capture_kernel(CaptureArgs a)
 {
     __shared__ DecodeScratch s;
     __shared__ uint32_t s_slot;
+    // the capture spans 3374 * sps samples = at most 845 ring words (sps <= 16): fetched once, coalesced, into LDS; the
+    // first version had every lane fetch its 53 words one dependent 8-byte load at a time
+    constexpr int MAXW = (AMPS_RECC_CAPTURE_SYMS * 16) / 64 + 3;
+    __shared__ uint64_t s_ring[MAXW];
     const int lane = threadIdx.x;
     uint32_t ncap = *a.capq_count;
     if (ncap > a.capq_cap) ncap = a.capq_cap;
@@ -157,10 +161,13 @@ __global__ __launch_bounds__(64) void recc_capture_kernel(CaptureArgs a)
         const uint32_t c = (uint32_t)(e >> 40);
         const uint64_t nc = e & ((1ull << 40) - 1);
         const uint64_t *ring = a.gring + (uint64_t)c * a.ring_words;
+        const uint64_t w0 = (nc + a.sps) >> 6;
+        const int nw = (int)(((nc + (uint64_t)a.sps * AMPS_RECC_CAPTURE_SYMS) >> 6) - w0) + 1;
+        for (int i = lane; i < nw; i += 64) s_ring[i] = ring[(w0 + (uint64_t)i) & a.ring_mask];
+        __syncthreads();
         for (int i = lane; i < AMPS_RECC_CAPTURE_SYMS; i += 64) {
-            uint64_t n = nc + (uint64_t)a.sps * (uint64_t)(i + 1);
-            uint64_t w = ring[(n >> 6) & a.ring_mask];
-            s.sym[i] = (uint8_t)((w >> (n & 63)) & 1ull);
+            const uint64_t n = nc + (uint64_t)a.sps * (uint64_t)(i + 1);
+            s.sym[i] = (uint8_t)((s_ring[(n >> 6) - w0] >> (n & 63)) & 1ull);
         }
         if (lane == 0) s_slot = atomicAdd(a.nrecords, 1u);
         __syncthreads();
