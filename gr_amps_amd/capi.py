@@ -82,6 +82,7 @@ EXPORTS = (
     "amps_recc_get_timing", "amps_recc_reply_words", "amps_recc_debug_channelize",
     "amps_bch_encode_words", "amps_bch_decode_words",
     "amps_recc_set_xlate", "amps_recc_push_raw", "amps_recc_debug_xlate", "amps_recc_set_timing",
+    "amps_recc_drain_begin", "amps_recc_drain_end",
 )
 
 _lib = None
@@ -117,6 +118,8 @@ def load():
     L.amps_recc_push_iq.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int]
     L.amps_recc_push_wideband.argtypes = [vp, vp, C.c_size_t, C.c_int]
     L.amps_recc_drain.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.amps_recc_drain_begin.argtypes = [vp]
+    L.amps_recc_drain_end.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.amps_recc_debug_demod.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, vp, vp]
     L.amps_recc_get_timing.argtypes = [vp, C.POINTER(Timing), C.c_int]
     L.amps_recc_set_timing.argtypes = [vp, C.c_int]
@@ -336,6 +339,24 @@ class Recc:
         rc = load().amps_recc_drain(self._h, _hostptr(out), cap, C.byref(nout))
         if rc:
             raise AmpsError(rc, "amps_recc_drain")
+        return out[:nout.value].copy() if copy else out[:nout.value]
+
+    def drain_begin(self):
+        """Close the current record list without waiting; pushes issued after this append to a second list."""
+        rc = load().amps_recc_drain_begin(self._h)
+        if rc:
+            raise AmpsError(rc, "amps_recc_drain_begin")
+
+    def drain_end(self, cap=None, copy=True):
+        """Wait for the work enqueued before drain_begin() only, and return its records (sorted)."""
+        cap = cap or self.max_bursts
+        out = getattr(self, "_drain_buf", None)
+        if out is None or out.shape[0] < cap:
+            out = self._drain_buf = np.empty(cap, BURST_DTYPE)
+        nout = C.c_size_t(0)
+        rc = load().amps_recc_drain_end(self._h, _hostptr(out), cap, C.byref(nout))
+        if rc:
+            raise AmpsError(rc, "amps_recc_drain_end")
         return out[:nout.value].copy() if copy else out[:nout.value]
 
     def debug_demod(self, iq):

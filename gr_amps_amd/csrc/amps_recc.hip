@@ -65,7 +65,12 @@ struct amps_recc {
     uint32_t *nrecords = nullptr;
     uint32_t *status = nullptr;
     amps_recc_burst_t *rec_host = nullptr;   // mapped pinned host memory: the capture kernel writes records here directly
-    uint32_t *hdr_host = nullptr;             // pinned {nrecords, status}
+    uint32_t *hdr_host = nullptr;             // pinned {nrecords, status} per record list
+    // two record lists: pushes append to the current one; drain_begin closes it (and switches), drain_end collects it
+    amps_recc_burst_t *rec_host_buf[2] = { nullptr, nullptr }, *records_buf[2] = { nullptr, nullptr };
+    uint32_t *nrecords_buf[2] = { nullptr, nullptr }, *status_buf[2] = { nullptr, nullptr };
+    int cur_buf = 0, open_buf = -1;
+    hipEvent_t drain_event = nullptr;
     float2 *stage_iq = nullptr;       // device staging for host-resident IQ
     size_t stage_iq_samples = 0;
 
@@ -137,9 +142,11 @@ struct SpanGuard {   // records a pair of events around a launch when timing is 
     }
 };
 
-void collect_spans(amps_recc *h)   // stream must be synchronised
+void collect_spans(amps_recc *h)   // collects the spans whose events have completed (all of them after a stream sync)
 {
+    size_t keep = 0;
     for (auto &s : h->spans) {
+        if (hipEventQuery(s.b) != hipSuccess) { h->spans[keep++] = s; continue; }
         float t = 0.f;
         if (hipEventElapsedTime(&t, s.a, s.b) == hipSuccess) {
             h->ms[s.tag] += t;
@@ -149,7 +156,7 @@ void collect_spans(amps_recc *h)   // stream must be synchronised
         h->event_pool.push_back(s.a);
         h->event_pool.push_back(s.b);
     }
-    h->spans.clear();
+    h->spans.resize(keep);
 }
 
 // AMPS_RECC_DEBUG_SYNC=1: synchronise after every launch and say which kernel ran (fault isolation)
@@ -168,6 +175,13 @@ int debug_sync(amps_recc *h, const char *what)
     return e == hipSuccess ? 0 : -EIO;
 }
 
+void select_record_list(amps_recc *h, int b)
+{
+    h->cur_buf = b;
+    h->records = h->records_buf[b]; h->rec_host = h->rec_host_buf[b];
+    h->nrecords = h->nrecords_buf[b]; h->status = h->status_buf[b];
+}
+
 constexpr uint64_t MIN_SPAN = 16;   // tiles per wave at least: bounds the 2-tile halo overhead to 12.5 % on tiny pushes
 
 uint32_t next_pow2(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return (uint32_t)p; }
@@ -184,8 +198,12 @@ int reset_state(amps_recc *h)
         HIP_TRY(hipMemsetAsync(h->pending, 0xff, sizeof(uint64_t) * h->C, s));
         HIP_TRY(hipMemsetAsync(h->capq_count, 0, sizeof(uint32_t), s));
     }
-    HIP_TRY(hipMemsetAsync(h->nrecords, 0, sizeof(uint32_t), s));
-    HIP_TRY(hipMemsetAsync(h->status, 0, sizeof(uint32_t), s));
+    for (int b = 0; b < 2; b++) {
+        HIP_TRY(hipMemsetAsync(h->nrecords_buf[b], 0, sizeof(uint32_t), s));
+        HIP_TRY(hipMemsetAsync(h->status_buf[b], 0, sizeof(uint32_t), s));
+    }
+    h->open_buf = -1;
+    select_record_list(h, 0);
     HIP_TRY(hipMemsetAsync(h->symbuf, 0, (size_t)h->C * AMPS_RECC_SYMBUF, s));
     HIP_TRY(hipMemsetAsync(h->sym_len, 0, sizeof(uint32_t) * h->C, s));
     HIP_TRY(hipMemsetAsync(h->sym_cur, 0xff, sizeof(int32_t) * h->C, s));
@@ -393,8 +411,7 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
     int rc = 0;
     const size_t C = h->C;
     // results + symbol seam (always present)
-    rc |= dev_alloc(&h->nrecords, 1);
-    rc |= dev_alloc(&h->status, 1);
+    for (int b = 0; b < 2; b++) { rc |= dev_alloc(&h->nrecords_buf[b], 1); rc |= dev_alloc(&h->status_buf[b], 1); }
     rc |= dev_alloc(&h->symbuf, C * AMPS_RECC_SYMBUF);
     rc |= dev_alloc(&h->sym_len, C);
     rc |= dev_alloc(&h->sym_cur, C);
@@ -404,9 +421,12 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
     rc |= dev_alloc(&h->nbursts_dev, 1);
     // result records live in mapped, pinned host memory (zero copy: 728 B per burst over PCIe while the
     // kernels run); h->records is the device-side view of the same allocation
-    if (hipHostMalloc((void **)&h->rec_host, sizeof(amps_recc_burst_t) * (size_t)cfg->max_bursts, hipHostMallocMapped) != hipSuccess ||
-        hipHostGetDevicePointer((void **)&h->records, h->rec_host, 0) != hipSuccess) rc |= -ENOMEM;
-    if (hipHostMalloc((void **)&h->hdr_host, 2 * sizeof(uint32_t)) != hipSuccess) rc |= -ENOMEM;
+    for (int b = 0; b < 2; b++)
+        if (hipHostMalloc((void **)&h->rec_host_buf[b], sizeof(amps_recc_burst_t) * (size_t)cfg->max_bursts, hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void **)&h->records_buf[b], h->rec_host_buf[b], 0) != hipSuccess) rc |= -ENOMEM;
+    if (hipHostMalloc((void **)&h->hdr_host, 4 * sizeof(uint32_t)) != hipSuccess) rc |= -ENOMEM;
+    if (hipEventCreateWithFlags(&h->drain_event, hipEventDisableTiming) != hipSuccess) rc |= -ENOMEM;
+    if (!rc) select_record_list(h, 0);
     // IQ seam
     if (!rc && cfg->max_samples_per_push) {
         const uint64_t maxs = cfg->max_samples_per_push;
@@ -446,11 +466,12 @@ void amps_recc_destroy(amps_recc_t *h)
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
     h->event_pool.clear();
     void *bufs[] = { h->carry[0], h->carry[1], h->gring, h->det, h->detcount, h->next_allowed, h->pending, h->capq,
-                     h->capq_count, h->nrecords, h->status, h->stage_iq, h->symbuf, h->sym_len, h->sym_cur,
+                     h->capq_count, h->nrecords_buf[0], h->nrecords_buf[1], h->status_buf[0], h->status_buf[1], h->stage_iq, h->symbuf, h->sym_len, h->sym_cur,
                      h->sym_stage, h->bursts_dev, h->burst_chan_dev, h->nbursts_dev, h->dec_out_dev, h->dec_in_dev,
                      h->dec_chan_dev, h->dbg_d, h->dbg_S };
     for (void *p : bufs) if (p) (void)hipFree(p);
-    if (h->rec_host) (void)hipHostFree(h->rec_host);
+    for (int b = 0; b < 2; b++) if (h->rec_host_buf[b]) (void)hipHostFree(h->rec_host_buf[b]);
+    if (h->drain_event) (void)hipEventDestroy(h->drain_event);
     if (h->hdr_host) (void)hipHostFree(h->hdr_host);
     channelizer_destroy(h->chz);
     xlate_destroy(h->xl);
@@ -712,28 +733,44 @@ int amps_recc_debug_xlate(amps_recc_t *h, const float *iq, size_t ld, size_t nsa
     return 0;
 }
 
-int amps_recc_drain(amps_recc_t *h, amps_recc_burst_t *out, size_t cap, size_t *nout)
+int amps_recc_drain_begin(amps_recc_t *h)
+{
+    if (!h) return -EINVAL;
+    if (h->open_buf >= 0) return -EBUSY;
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const int b = h->cur_buf;
+    uint32_t *hdr = h->hdr_host + 2 * b;
+    HIP_TRY(hipMemcpyAsync(&hdr[0], h->nrecords_buf[b], sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&hdr[1], h->status_buf[b], sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(h->drain_event, s));
+    h->open_buf = b;
+    select_record_list(h, b ^ 1);           // later pushes append to the other list
+    return 0;
+}
+
+int amps_recc_drain_end(amps_recc_t *h, amps_recc_burst_t *out, size_t cap, size_t *nout)
 {
     if (!h || !nout) return -EINVAL;
     *nout = 0;
+    if (h->open_buf < 0) return -EINVAL;
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = h->stream;
-    uint32_t *hdr = h->hdr_host;
-    HIP_TRY(hipMemcpyAsync(&hdr[0], h->nrecords, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&hdr[1], h->status, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    const int b = h->open_buf;
+    HIP_TRY(hipEventSynchronize(h->drain_event));   // everything enqueued before drain_begin is done; later pushes may still run
     collect_spans(h);
+    const uint32_t *hdr = h->hdr_host + 2 * b;
     uint32_t n = hdr[0];
     int rc = 0;
     if (hdr[1] & 1u) rc = -EOVERFLOW;
     if ((hdr[1] & (2u | 4u)) || n > h->cfg.max_bursts) { rc = -ENOSPC; }
     if (n > h->cfg.max_bursts) n = h->cfg.max_bursts;
     if (n) {
-        // the records are already in host memory (written by the capture kernel, visible after the sync above);
+        // the records are already in host memory (written by the capture kernel, visible after the event above);
         // order by (channel, position) through compact 16-byte keys, then gather once into the caller's buffer
         struct Key { uint64_t k; uint32_t i; };
         std::vector<Key> keys(n);
-        const amps_recc_burst_t *r = h->rec_host;
+        const amps_recc_burst_t *r = h->rec_host_buf[b];
         for (uint32_t i = 0; i < n; i++) keys[i] = { ((uint64_t)r[i].channel << 40) | (r[i].position & ((1ull << 40) - 1)), i };
         std::sort(keys.begin(), keys.end(), [](const Key &x, const Key &y) { return x.k < y.k; });
         size_t k = std::min<size_t>(n, cap);
@@ -741,9 +778,21 @@ int amps_recc_drain(amps_recc_t *h, amps_recc_burst_t *out, size_t cap, size_t *
         *nout = k;
         if (n > cap) rc = -ENOSPC;
     }
-    HIP_TRY(hipMemsetAsync(h->nrecords, 0, sizeof(uint32_t), s));
-    HIP_TRY(hipMemsetAsync(h->status, 0, sizeof(uint32_t), s));
+    // the list is empty again before it becomes current (stream order: these precede every later push into it)
+    HIP_TRY(hipMemsetAsync(h->nrecords_buf[b], 0, sizeof(uint32_t), s));
+    HIP_TRY(hipMemsetAsync(h->status_buf[b], 0, sizeof(uint32_t), s));
+    h->open_buf = -1;
     return rc;
+}
+
+int amps_recc_drain(amps_recc_t *h, amps_recc_burst_t *out, size_t cap, size_t *nout)
+{
+    if (!h || !nout) return -EINVAL;
+    *nout = 0;
+    if (h->open_buf >= 0) return -EBUSY;     // finish the split drain first
+    int rc = amps_recc_drain_begin(h);
+    if (rc) return rc;
+    return amps_recc_drain_end(h, out, cap, nout);
 }
 
 int amps_recc_debug_demod(amps_recc_t *h, const float *iq, size_t nsamp, int mem, float *demod, float *soft, uint8_t *hard)

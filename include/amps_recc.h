@@ -214,6 +214,13 @@ int amps_recc_debug_xlate(amps_recc_t *h, const float *iq, size_t ld, size_t nsa
  * drain, sorted by (channel, position).  -ENOSPC if the device list overflowed max_bursts
  * (the first max_bursts records are still returned). */
 int amps_recc_drain(amps_recc_t *h, amps_recc_burst_t *out, size_t cap, size_t *nout);
+/* Split drain for streaming callers that must not idle the GPU while the host collects results:
+ *     push(n); drain_begin();  push(n+1);  drain_end(&records of everything pushed before drain_begin) ...
+ * drain_begin closes the current record list without waiting (later pushes append to a second list);
+ * drain_end waits only for the work enqueued before drain_begin.  At most one split drain is open
+ * (-EBUSY otherwise); amps_recc_drain == drain_begin + drain_end. */
+int amps_recc_drain_begin(amps_recc_t *h);
+int amps_recc_drain_end(amps_recc_t *h, amps_recc_burst_t *out, size_t cap, size_t *nout);
 
 /* test/diagnostic taps (not on the hot path): FM-demod floats and sliced symbol bits of one
  * channel for the last push_iq() call.  demod/soft/hard are host arrays of length n (may be NULL). */
