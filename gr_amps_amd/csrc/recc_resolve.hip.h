@@ -39,25 +39,27 @@ constexpr int RESOLVE_LDS_HITS = 2048;
 
 // One workgroup per channel.  The hit lists of a channel's wave segments are ordered but scattered
 // (up to thousands of segments when one channel is pushed 2^26 samples at a time): 256 (or 1024) lanes compact them into
-// LDS with a block-wide prefix sum (coalesced count loads, independent hit loads), then wave 0 does the hold-off
-// walk -- sequential by nature, but now on LDS instead of a chain of dependent HBM reads (0.72 ms -> see DESIGN.md).
+// LDS with a block-wide prefix sum (coalesced count loads, independent hit loads); the hold-off walk then runs on LDS,
+// split into independent chains (see below).  0.72 ms -> 0.09 (LDS, one lane) -> parallel chains, for one channel x 2^26.
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void recc_resolve_kernel(ResolveArgs a)
 {
     __shared__ uint64_t s_hits[RESOLVE_LDS_HITS];
     __shared__ uint32_t s_scan[THREADS];
     __shared__ uint64_t s_acc[RESOLVE_LDS_HITS + 1];               // +1: the pending capture of an earlier push
+    __shared__ uint8_t  s_head[RESOLVE_LDS_HITS], s_accf[RESOLVE_LDS_HITS];
+    __shared__ uint64_t s_na_out, s_pend;
     __shared__ uint32_t s_total, s_nacc, s_base;
     const int c = blockIdx.x, tid = threadIdx.x;
     const uint64_t span_hold = (uint64_t)a.sps * (AMPS_RECC_CAPTURE_SYMS + AMPS_RECC_TRIGGER_SYMS);
     const uint64_t span_done = (uint64_t)a.sps * (AMPS_RECC_CAPTURE_SYMS + 1);
-    uint64_t next_allowed = a.next_allowed[c];
+    uint64_t next_allowed = a.next_allowed[c];                        // uniform across the block
     uint64_t pend = a.pending[c];
+    auto centre = [](uint64_t ei) -> uint64_t { return (ei >> 8) + (uint32_t)(ei & 0xff) / 2; };   // of the run of matching phases
 
     // accepted captures are collected in LDS and published with ONE atomicAdd per batch: a global atomic per burst
-    // is a ~0.4 us round trip on the sequential walk
-    uint32_t nacc = 0;                                                // wave 0 only, uniform
-    auto flush = [&]() {                                              // all 256 threads
+    // is a ~0.4 us round trip
+    auto flush = [&]() {                                              // all threads
         __syncthreads();
         const uint32_t m = s_nacc;
         if (m) {
@@ -71,9 +73,9 @@ __global__ __launch_bounds__(THREADS) void recc_resolve_kernel(ResolveArgs a)
         }
         __syncthreads();
     };
+    if (tid == 0) s_nacc = 0;
     if (pend != ~0ull && pend + span_done < a.n_proc) {
-        if (tid == 0) s_acc[0] = pend;
-        nacc = 1;
+        if (tid == 0) { s_acc[0] = pend; s_nacc = 1; }
         pend = ~0ull;
     }
 
@@ -84,10 +86,11 @@ __global__ __launch_bounds__(THREADS) void recc_resolve_kernel(ResolveArgs a)
     const uint64_t *det = a.det + (uint64_t)c * a.max_chunks * a.det_cap;
 
     for (uint32_t cb = 0; cb < nchunks; cb += THREADS) {
-        // ---- compaction of up to 256 segments into LDS, order preserved
+        // ---- compaction of up to THREADS segments into LDS, order preserved
         const uint32_t ch = cb + tid;
         const uint32_t n = ch < nchunks ? cnt[ch] : 0u;
         s_scan[tid] = n;
+        if (tid == 0) { s_pend = ~0ull; s_na_out = next_allowed; }
         __syncthreads();
         for (int off = 1; off < THREADS; off <<= 1) {       // Hillis-Steele inclusive scan
             uint32_t v = tid >= off ? s_scan[tid - off] : 0u;
@@ -103,31 +106,42 @@ __global__ __launch_bounds__(THREADS) void recc_resolve_kernel(ResolveArgs a)
             else atomicOr(a.status, 1u);                              // more hits than one batch can hold
         }
         __syncthreads();
-        // ---- hold-off walk (wave 0): every lane follows the same scalar path
-        if (tid < 64) {
-            const uint32_t total = s_total < RESOLVE_LDS_HITS ? s_total : RESOLVE_LDS_HITS;
-            for (uint32_t b = 0; b < total; b += 64) {                // 64 hits per LDS read, then readlane
-                const uint64_t mine = b + tid < total ? s_hits[b + tid] : 0ull;
-                const uint32_t mlo = (uint32_t)mine, mhi = (uint32_t)(mine >> 32);
-                const uint32_t m = total - b < 64u ? total - b : 64u;
-                for (uint32_t j = 0; j < m; j++) {
-                    const uint64_t ei = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mhi, (int)j) << 32) |
-                                        (uint32_t)__builtin_amdgcn_readlane((int)mlo, (int)j);
-                    const uint64_t astart = ei >> 8;
-                    const uint32_t last = (uint32_t)(ei & 0xff);
-                    if (astart < next_allowed) continue;              // inside an accepted burst
-                    const uint64_t nc = astart + last / 2;            // centre of the run of matching phases
-                    next_allowed = nc + span_hold;
-                    if (nc + span_done < a.n_proc) s_acc[nacc++] = nc;    // all lanes store the same value: no branch
-                    else pend = nc;                                   // tail not received yet
-                }
-            }
-            if (tid == 0) s_nacc = nacc;
-            nacc = 0;
+        const uint32_t total = s_total < RESOLVE_LDS_HITS ? s_total : RESOLVE_LDS_HITS;
+        // ---- hold-off walk.  The rule is sequential (a hit is dropped iff it starts inside the hold-off of the last
+        // ACCEPTED hit), but a hit that starts at least one hold-off after the CENTRE of its predecessor is outside every
+        // earlier burst whatever was accepted (hits are ordered, so every earlier centre is <= that one): it is accepted
+        // unconditionally and heads a new chain.  Chains are walked independently, one lane each; real traffic has one
+        // hit per chain (one lane did all of it before: 125 ns per hit, 0.09 ms for the 745 bursts of one channel x 2^26).
+        for (uint32_t j = tid; j < total; j += THREADS)
+            s_head[j] = (j == 0) || ((s_hits[j] >> 8) >= centre(s_hits[j - 1]) + span_hold);
+        __syncthreads();
+        for (uint32_t j = tid; j < total; j += THREADS) {
+            if (!s_head[j]) continue;
+            uint64_t na = j == 0 ? next_allowed : 0ull;               // hit 0 continues the state carried into this batch
+            uint32_t k = j;
+            do {
+                const uint64_t ei = s_hits[k];
+                const bool acc = (ei >> 8) >= na;
+                if (acc) na = centre(ei) + span_hold;
+                s_accf[k] = (uint8_t)acc;
+                k++;
+            } while (k < total && !s_head[k]);
+            if (k == total) s_na_out = na;                            // the last chain carries the state out
         }
+        __syncthreads();
+        for (uint32_t j = tid; j < total; j += THREADS) {
+            if (!s_accf[j]) continue;
+            const uint64_t nc = centre(s_hits[j]);
+            if (nc + span_done < a.n_proc) s_acc[atomicAdd(&s_nacc, 1u)] = nc;   // order is irrelevant: drain sorts the records
+            else s_pend = nc;                                         // tail not received yet (at most one: the last)
+        }
+        __syncthreads();
+        next_allowed = s_na_out;
+        if (s_pend != ~0ull) pend = s_pend;
         flush();
+        if (tid == 0) s_nacc = 0;
     }
-    if (nchunks == 0) { if (tid == 0) s_nacc = nacc; flush(); }
+    if (nchunks == 0) flush();
     if (tid == 0) { a.next_allowed[c] = next_allowed; a.pending[c] = pend; }
 }
 

@@ -426,3 +426,45 @@ def test_split_drain_pipelines_pushes_and_loses_nothing(gpu):
     got = got[np.lexsort((got["position"], got["channel"]))]
     assert len(want) == sum(len(t) for t in truth)
     assert got.tobytes() == want.tobytes()
+
+
+def test_hold_off_chains_match_the_sequential_rule(gpu):
+    """Triggers that fall inside the hold-off of an accepted burst are dropped, the first one after it is accepted -- the
+    resolve kernel walks independent chains in parallel, the CPU model applies the rule hit by hit.  Truncated bursts put
+    several triggers inside one hold-off window; several channels with different patterns; one and many pushes."""
+    sps = 10
+    rng = np.random.default_rng(77)
+
+    def chan(pattern):
+        bursts, off = [], 3000
+        for gap_syms, keep_bits in pattern:
+            _, _, _, _, words = synth.random_message(rng)
+            bits = synth.burst_bits(words, dcc=int(rng.integers(0, 4)), rng=rng)
+            bursts.append((off, bits[:keep_bits]))
+            off += gap_syms * sps
+        return bursts, off
+
+    full = 41 + 7 + 7 * 240
+    patterns = [
+        [(1100, 400), (900, 400), (1500, full), (3600, full), (500, 300), (3500, full)],     # 2nd, 3rd inside the 1st's hold-off
+        [(3448, full), (3448, full), (3449, full), (4000, full)],                           # back to back at the hold-off boundary
+        [(200, 60), (200, 60), (200, 60), (200, 60), (3000, 60), (4000, full)],             # a burst of false starts
+    ]
+    built = [chan(p) for p in patterns]
+    N = max(off for _, off in built) + 40000
+    iq = np.stack([synth.fsk_modulate(N, b, sps=sps, fs=200e3, snr_db=30.0, rng=np.random.default_rng(5 + i)) for i, (b, _) in enumerate(built)])
+    want = oracle.fused_push_all(iq, sps=sps)
+    assert len(want) >= 6        # sanity: the patterns produce accepted and dropped triggers
+    for blocks in ([N], [50000, 1, 70000, N]):
+        with capi.Recc(n_channels=len(patterns), sps=sps, max_samples=N, max_bursts=256) as r:
+            off, recs = 0, []
+            for b in blocks:
+                b = min(b, N - off)
+                if b <= 0:
+                    break
+                r.push_iq(np.ascontiguousarray(iq[:, off:off + b]))
+                recs.append(r.drain())
+                off += b
+            got = np.concatenate(recs)
+        got = got[np.lexsort((got["position"], got["channel"]))]
+        assert got.tobytes() == want.tobytes()
