@@ -320,6 +320,13 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc
         for (int d = 0; d + 1 < DEPTH; d++) load_tile(nxt[d], chunk_start - HALO + (d + 1) * TILE);   // K >= 1: all exist up to d = 1
     }
     const uint32_t *gring32 = (const uint32_t *)(a.gring + (uint64_t)c * a.ring_words);
+    auto load_bits = [&](int kk) -> uint32_t {        // BITS mode: dword `lane` of tile kk of this segment (lanes 0..15)
+        if (lane >= TILE / 32) return 0u;
+        const int64_t n32 = (int64_t)a.n_done + chunk_start + (int64_t)kk * TILE + 32 * lane;
+        return n32 < 0 ? ~0u : gring32[(uint64_t)(n32 >> 5) & (2ull * a.ring_words - 1)];
+    };
+    uint32_t bw0 = 0u, bw1 = 0u, bw2 = 0u;           // tiles k, k+1, k+2 of the loop below (K >= 1)
+    if constexpr (BITS) { bw0 = load_bits(-2); bw1 = load_bits(-1); bw2 = load_bits(0); }
 
     // k = -2, -1 are the halo tiles [chunk_start-1024, chunk_start): recomputed, never stored or emitted
     for (int k = -2; k < K; k++) {
@@ -328,10 +335,12 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc
         float *const dcur = s_d + ((k + 2) & 1) * DBUF;        // demod buffer of this tile
         float *const dnxt = s_d + ((k + 3) & 1) * DBUF;        // ... of the next tile (gets our tail as history)
         if constexpr (BITS) {
-            // the tile's 512 slicer bits come from the HBM ring; samples before the stream are ones (x = 0 -> g = 1)
+            // the tile's 512 slicer bits come from the HBM ring (fetched three tiles ahead: a bare load per tile is ~1 us of
+            // exposed latency); samples before the stream are ones (x = 0 -> g = 1)
+            const uint32_t w = bw0;
+            bw0 = bw1; bw1 = bw2;
+            bw2 = (k + 3 < K) ? load_bits(k + 3) : 0u;
             if (lane < TILE / 32) {
-                const int64_t n32 = (int64_t)a.n_done + t0 + 32 * lane;
-                const uint32_t w = n32 < 0 ? ~0u : gring32[(uint64_t)(n32 >> 5) & (2ull * a.ring_words - 1)];
                 s_g[slot * (TILE / 32) + lane] = w;
                 if (slot == 0 && lane < 2) s_g[GW32 + lane] = w;      // mirror of dwords 0,1
             }

@@ -119,3 +119,35 @@ def test_fused_and_two_kernel_wideband_forms_agree(gpu):
         assert o.tobytes() == outs[0].tobytes()
     mins = sorted(v[1] for v in truth.values())
     assert sorted(g["min"].decode() for g in outs[0]) == mins
+
+
+def test_config2_64_channels_behind_the_channelizer(gpu):
+    """BASELINE configs[2]: 64 RECC channels (a sub-band of the 1024 bins) behind the polyphase channelizer.  Bursts in
+    the first, last and interior channels of the group and in channels just outside it (which must not be reported)."""
+    first, C = 200, 64
+    n = int(0.25 * sw.FS_WIDE) // D * D
+    inside = [(first + 0, 90000), (first + 63, 140000), (first + 17, 60000), (first + 18, 200000), (first + 40, 30000)]
+    outside = [(first - 1, 100000), (first + 64, 120000)]
+    x, truth = sw.make_wideband(n, inside + outside, seed=21)
+    with capi.Recc(n_channels=C, sps=3, max_samples=n // D + 72, max_bursts=64,
+                   wideband={"channels": 1024, "decim": 512, "taps_per_branch": 8, "first_channel": first}) as r:
+        chan = r.debug_channelize(x)
+    assert chan.shape[0] == C
+    with capi.Recc(n_channels=C, sps=3, max_samples=n // D + 72, max_bursts=64,
+                   wideband={"channels": 1024, "decim": 512, "taps_per_branch": 8, "first_channel": first}) as r:
+        for part in np.array_split(x, 3):
+            r.push_wideband(part)
+        r.push_wideband(np.zeros(64 * D, np.complex64))
+        got = r.drain()
+    assert sorted(int(g["channel"]) for g in got) == sorted(k - first for k, _ in inside)
+    by_chan = {int(g["channel"]): g for g in got}
+    for (k, off), (kind, min10, esn, dialed, words) in truth.items():
+        if not (first <= k < first + C):
+            continue
+        g = by_chan[k - first]
+        assert g["min"].decode() == min10 and g["valid"].all()
+        for w, bits in enumerate(words):
+            assert list(g["word_raw"][w][:36]) == list(bits)
+    want = oracle.fused_push_all(chan, sps=3)
+    assert [(int(w["channel"]), w["min"]) for w in want] == [(int(g["channel"]), g["min"]) for g in got]
+    assert all(np.array_equal(a["word_raw"], b["word_raw"]) and np.array_equal(a["word_dec"], b["word_dec"]) for a, b in zip(want, got))
