@@ -92,7 +92,7 @@ struct BchResult {
 // root search over all 63 positions (in the order j = 0..62, root alpha^j <-> exponent (63 - j) % 63), failure iff
 // #roots != deg(Lambda).  Roots in the 15 padding positions are NOT rejected (the reference does not check them,
 // SURVEY.md 8a R4).
-__device__ inline BchResult bch63_decode_packed(uint64_t w)
+__device__ __forceinline__ BchResult bch63_decode_packed(uint64_t w)
 {
     BchResult r;
     r.ok = 0; r.nflip = 0; r.e[0] = r.e[1] = r.e[2] = -1;
@@ -138,17 +138,28 @@ __device__ inline BchResult bch63_decode_packed(uint64_t w)
 }
 
 // bits: nbits bytes (0/1), bit i is the coefficient of x^(nbits-1-i); the shortening zeros sit above x^(nbits-1).
-__device__ inline BchResult bch_short_decode(const uint8_t *bits, int nbits)
+__device__ __forceinline__ BchResult bch_short_decode(const uint8_t *bits, int nbits)
 {
     uint64_t w = 0;
     for (int i = 0; i < nbits; i++) w |= (uint64_t)(bits[i] & 1u) << (nbits - 1 - i);
     return bch63_decode_packed(w);
 }
 
-__device__ inline BchResult bch4836_decode(const uint8_t *bits) { return bch_short_decode(bits, 48); }
+__device__ __forceinline__ BchResult bch4836_decode(const uint8_t *bits) { return bch_short_decode(bits, 48); }
+
+// the same for a block of 48 bit-bytes (0/1) at an 8-byte aligned address: six 64-bit reads, each packed to a byte by one
+// multiply (first byte -> most significant bit), instead of 48 dependent one-byte LDS reads
+__device__ __forceinline__ BchResult bch4836_decode_aligned(const uint8_t *bits)
+{
+    const uint64_t *p = (const uint64_t *)bits;
+    uint64_t w = 0;
+#pragma unroll
+    for (int c = 0; c < 6; c++) w |= ((p[c] * 0x8040201008040201ull) >> 56) << (40 - 8 * c);
+    return bch63_decode_packed(w);
+}
 
 // systematic encode of k message bits: parity = m(x) x^12 mod g(x), g = x^12+x^10+x^8+x^5+x^4+x^3+1
-__device__ inline void bch_short_encode(const uint8_t *msg, int k, uint8_t *cw)
+__device__ __forceinline__ void bch_short_encode(const uint8_t *msg, int k, uint8_t *cw)
 {
     unsigned rem = 0;
     for (int j = 0; j < k; j++) {
@@ -168,7 +179,7 @@ __device__ __forceinline__ unsigned getbits(const uint8_t *b, int n)
 }
 
 // lib/amps_packet.h:277-302 (quirks kept: dig>9 -> 0)
-__device__ inline void extract_min_3(unsigned val, char *out)
+__device__ __forceinline__ void extract_min_3(unsigned val, char *out)
 {
     unsigned m2 = val + 111;
     unsigned dig = m2 % 10;
@@ -183,18 +194,21 @@ __device__ inline void extract_min_3(unsigned val, char *out)
 }
 
 // LDS scratch one wave needs to decode a burst
+constexpr int BOFF = 1;                         // bit k of the burst lives at bits[BOFF + k]: the word blocks start at 8 + 240 w + 48 r
 struct DecodeScratch {
     uint8_t  sym[AMPS_RECC_CAPTURE_SYMS + 2];   // symbol bytes
-    uint8_t  bits[1688];                        // dcc(7) + 7*240
+    uint8_t  bits[1696];                        // [BOFF + k], k < 7 + 7*240: dcc(7) then the words; BOFF makes every 48-bit block 8-byte aligned
     uint32_t bad[8];                            // [0]=dcc, [1+w]=word w
     uint32_t nonbin;
     int8_t   ok[35];
     int8_t   flip[35][3];
+    int8_t   rr[8];                             // repeat whose bits become word_dec[w]
+    uint64_t packed[7];                         // the words the field parser reads, bit-reversed: bit 63-i = word bit i
     amps_recc_burst_t rec;                      // staged record (728 B), copied out coalesced
 };
 
 // Decode the burst held in s.sym; all 64 lanes of ONE wave must call this (blockDim.x == 64).
-__device__ inline void decode_burst_wave(DecodeScratch &s, uint32_t channel, uint64_t position,
+__device__ __forceinline__ void decode_burst_wave(DecodeScratch &s, uint32_t channel, uint64_t position,
                                          amps_recc_burst_t *__restrict__ out, bool majority = false)
 {
     const int lane = threadIdx.x & 63;
@@ -204,18 +218,25 @@ __device__ inline void decode_burst_wave(DecodeScratch &s, uint32_t channel, uin
     for (int i = lane; i < (int)(sizeof(amps_recc_burst_t) / 4); i += 64) ((uint32_t *)&s.rec)[i] = 0;
     __syncthreads();
 
-    // ---- Manchester decode, lib/utils.cc:27-59 ----
-    for (int k = lane; k < 1687; k += 64) {
-        unsigned a = s.sym[2 * k], b = s.sym[2 * k + 1];
-        unsigned sval = (a << 8) | b;
-        uint8_t bit; int bad = 0;
-        if (sval == 0x100) bit = 0;
-        else if (sval == 0x001) bit = 1;
-        else if (sval == 0x101) { bit = 0; bad = 1; }
-        else if (sval == 0x000) { bit = 1; bad = 1; }
-        else { bit = 0; bad = 1; atomicOr(&s.nonbin, 1u); }   // reference: assert(0), undefined in Release
-        s.bits[k] = bit;
-        if (bad) atomicAdd(&s.bad[k < 7 ? 0 : 1 + (k - 7) / 240], 1u);
+    // ---- Manchester decode, lib/utils.cc:27-59: (1,0) -> 0, (0,1) -> 1, (1,1) -> 0 + bad, (0,0) -> 1 + bad; a byte outside
+    // {0,1} is undefined in the reference (assert(0) compiled out): bit 0 + bad + flag.  Branch-free on one 16-bit read per
+    // pair so the 27 rounds pipeline (the four-way if/else with byte reads cost 5 us per burst).
+    {
+        const uint16_t *s16 = (const uint16_t *)s.sym;
+#pragma unroll 9
+        for (int it = 0; it < 27; it++) {
+            const int k = lane + 64 * it;
+            if (k < 1687) {
+                const unsigned pr = s16[k];
+                const unsigned sa = pr & 0xffu, sb = pr >> 8;
+                const bool nonbin = (sa | sb) > 1u;
+                const bool same = sa == sb;
+                const unsigned bit = nonbin ? 0u : (same ? (sa ^ 1u) : sb);
+                s.bits[BOFF + k] = (uint8_t)bit;
+                if (nonbin) atomicOr(&s.nonbin, 1u);
+                if (nonbin || same) atomicAdd(&s.bad[k < 7 ? 0 : 1 + (k - 7) / 240], 1u);
+            }
+        }
     }
     __syncthreads();
 
@@ -224,7 +245,7 @@ __device__ inline void decode_burst_wave(DecodeScratch &s, uint32_t channel, uin
         // ---- BCH: 7 words x 5 repeats, lib/recc_decode_impl.cc:100-107 ----
         if (lane < 35) {
             const int w = lane / 5, r = lane % 5;
-            BchResult br = bch4836_decode(&s.bits[7 + 240 * w + 48 * r]);
+            BchResult br = bch4836_decode_aligned(&s.bits[BOFF + 7 + 240 * w + 48 * r]);
             s.ok[lane] = (int8_t)br.ok;
             s.flip[lane][0] = (int8_t)br.e[0];
             s.flip[lane][1] = (int8_t)br.e[1];
@@ -238,24 +259,30 @@ __device__ inline void decode_burst_wave(DecodeScratch &s, uint32_t channel, uin
             o.valid[w] = (uint8_t)ok;
             o.first_valid_rep[w] = (uint8_t)r;
             o.manch_bad[w] = (uint16_t)s.bad[1 + w];
-            const int rr = ok ? r : 4;
-            const uint8_t *src = &s.bits[7 + 240 * w + 48 * rr];
-            for (int i = 0; i < 36; i++) o.word_dec[w][i] = src[i];
-            if (ok) {
-                for (int f = 0; f < 3; f++) {
-                    int e = s.flip[w * 5 + rr][f];
-                    if (e >= 12 && e <= 47) o.word_dec[w][47 - e] ^= 1u;
-                }
-            }
+            s.rr[w] = (int8_t)(ok ? r : 4);
         }
         // raw repeat 0 of every word (what the reference parses)
-        for (int i = lane; i < 7 * 48; i += 64) o.word_raw[i / 48][i % 48] = s.bits[7 + 240 * (i / 48) + (i % 48)];
+        for (int i = lane; i < 7 * 48; i += 64) o.word_raw[i / 48][i % 48] = s.bits[BOFF + 7 + 240 * (i / 48) + (i % 48)];
+        __syncthreads();
+        // word_dec = the 36 message bits of the first valid repeat (or of repeat 4), copied by all lanes, then corrected
+        for (int i = lane; i < 7 * 36; i += 64) {
+            const int w = i / 36, b = i % 36;
+            o.word_dec[w][b] = s.bits[BOFF + 7 + 240 * w + 48 * s.rr[w] + b];
+        }
+        __syncthreads();
+        if (lane < 7 && o.valid[lane]) {
+            const int w = lane;
+            for (int f = 0; f < 3; f++) {
+                int e = s.flip[w * 5 + s.rr[w]][f];
+                if (e >= 12 && e <= 47) o.word_dec[w][47 - e] ^= 1u;
+            }
+        }
     } else {
         // ---- majority mode: bitwise 3-of-5 vote, one BCH decode per word, pad corrections rejected ----
         for (int i = lane; i < 7 * 48; i += 64) {
             const int w = i / 48, b = i % 48;
             int cnt = 0;
-            for (int r = 0; r < 5; r++) cnt += s.bits[7 + 240 * w + 48 * r + b];
+            for (int r = 0; r < 5; r++) cnt += s.bits[BOFF + 7 + 240 * w + 48 * r + b];
             o.word_raw[w][b] = (uint8_t)(cnt >= 3);
         }
         __syncthreads();
@@ -268,7 +295,7 @@ __device__ inline void decode_burst_wave(DecodeScratch &s, uint32_t channel, uin
             int agree = 0;
             for (int r = 0; r < 5; r++) {
                 int same = 1;
-                for (int b = 0; b < 48; b++) if (s.bits[7 + 240 * w + 48 * r + b] != o.word_raw[w][b]) { same = 0; break; }
+                for (int b = 0; b < 48; b++) if (s.bits[BOFF + 7 + 240 * w + 48 * r + b] != o.word_raw[w][b]) { same = 0; break; }
                 agree += same;
             }
             o.first_valid_rep[w] = (uint8_t)agree;
@@ -277,7 +304,16 @@ __device__ inline void decode_burst_wave(DecodeScratch &s, uint32_t channel, uin
             if (ok) for (int f = 0; f < 3; f++) { int e = br.e[f]; if (e >= 12 && e <= 47) o.word_dec[w][47 - e] ^= 1u; }
         }
     }
-    if (lane < 7) o.dcc[lane] = s.bits[lane];
+    if (lane < 7) o.dcc[lane] = s.bits[BOFF + lane];
+    __syncthreads();
+    // pack the seven words the parser reads (one ballot each): the field extraction below is then shifts on registers
+    // instead of ~250 dependent one-byte LDS reads by a single lane (7 us of a 25 us burst)
+    for (int w = 0; w < 7; w++) {
+        const uint8_t *src = majority ? o.word_dec[w] : o.word_raw[w];
+        const unsigned bit = lane < 36 ? (src[lane] & 1u) : 0u;   // every field lies inside the 36 message bits
+        const uint64_t m = __ballot(bit != 0);
+        if (lane == 0) s.packed[w] = __brevll(m);
+    }
     __syncthreads();
 
     // ---- field parse + dispatch: one lane, negligible work (lib/amps_packet.h, recc_decode_impl.cc:108-168) ----
@@ -289,8 +325,9 @@ __device__ inline void decode_burst_wave(DecodeScratch &s, uint32_t channel, uin
         // reference mode parses the raw repeat 0 (lib/recc_decode_impl.cc:112,117); majority mode the corrected word.
         // word_dec holds 36 bits = everything the field parsers read (the last 12 of the 48 are parity).
         bool used_ok = true;             // majority mode: every word the dispatch reads must have decoded
-        auto W = [&](int w) -> const uint8_t * { used_ok = used_ok && o.valid[w]; return majority ? o.word_dec[w] : o.word_raw[w]; };
-        const uint8_t *A = W(0), *B = W(1);
+        auto W = [&](int w) -> uint64_t { used_ok = used_ok && o.valid[w]; return s.packed[w]; };
+        auto fld = [](uint64_t wp, int off, int n) -> unsigned { return (unsigned)((wp >> (64 - off - n)) & ((1ull << n) - 1ull)); };   // MSB first
+        const uint64_t A = W(0), B = W(1);
         if (majority) {   // coded DCC: 0000000 / 0011111 / 1100011 / 1111100, accept within one bit
             const unsigned codes[4] = { 0x00, 0x1f, 0x63, 0x7c };
             unsigned d = getbits(o.dcc, 7);
@@ -298,14 +335,14 @@ __device__ inline void decode_burst_wave(DecodeScratch &s, uint32_t channel, uin
             for (int i = 0; i < 4; i++) if (__popc(d ^ codes[i]) <= 1) good = true;
             if (!good) o.flags |= AMPS_BURST_FLAG_DCC_INVALID;
         }
-        o.a_F = A[0] & 1u; o.a_NAWC = (uint8_t)getbits(A + 1, 3);
-        o.a_T = A[4] & 1u; o.a_S = A[5] & 1u; o.a_E = A[6] & 1u; o.a_ER = A[7] & 1u;
-        o.a_SCM = (uint8_t)getbits(A + 8, 4); o.a_MIN1 = getbits(A + 12, 24);
-        o.b_F = B[0] & 1u; o.b_NAWC = (uint8_t)getbits(B + 1, 3);
-        o.b_MSG_TYPE = (uint8_t)getbits(B + 4, 5); o.b_ORDQ = (uint8_t)getbits(B + 9, 3);
-        o.b_ORDER = (uint8_t)getbits(B + 12, 5); o.b_LT = B[17] & 1u; o.b_EP = B[18] & 1u;
-        o.b_SCM4 = B[19]; o.b_MPCI = (uint8_t)getbits(B + 20, 2); o.b_SDCC1 = (uint8_t)getbits(B + 22, 2);
-        o.b_SDCC2 = (uint8_t)getbits(B + 24, 2); o.b_MIN2 = (uint16_t)getbits(B + 26, 10);
+        o.a_F = (uint8_t)fld(A, 0, 1); o.a_NAWC = (uint8_t)fld(A, 1, 3);
+        o.a_T = (uint8_t)fld(A, 4, 1); o.a_S = (uint8_t)fld(A, 5, 1); o.a_E = (uint8_t)fld(A, 6, 1); o.a_ER = (uint8_t)fld(A, 7, 1);
+        o.a_SCM = (uint8_t)fld(A, 8, 4); o.a_MIN1 = fld(A, 12, 24);
+        o.b_F = (uint8_t)fld(B, 0, 1); o.b_NAWC = (uint8_t)fld(B, 1, 3);
+        o.b_MSG_TYPE = (uint8_t)fld(B, 4, 5); o.b_ORDQ = (uint8_t)fld(B, 9, 3);
+        o.b_ORDER = (uint8_t)fld(B, 12, 5); o.b_LT = (uint8_t)fld(B, 17, 1); o.b_EP = (uint8_t)fld(B, 18, 1);
+        o.b_SCM4 = (uint8_t)fld(B, 19, 1); o.b_MPCI = (uint8_t)fld(B, 20, 2); o.b_SDCC1 = (uint8_t)fld(B, 22, 2);
+        o.b_SDCC2 = (uint8_t)fld(B, 24, 2); o.b_MIN2 = (uint16_t)fld(B, 26, 10);
         // calc_min, lib/amps_packet.h:354-363
         extract_min_3(o.b_MIN2, o.min);
         extract_min_3((o.a_MIN1 >> 14) & 0x3ff, o.min + 3);
@@ -322,27 +359,27 @@ __device__ inline void decode_burst_wave(DecodeScratch &s, uint32_t channel, uin
             o.msg_class = AMPS_MSG_REGISTRATION;
             o.has_esn = o.a_S;
             if (o.a_S && o.a_NAWC > 1) {
-                const uint8_t *Cw = W(2);
-                o.esn = getbits(Cw + 4, 32);
+                const uint64_t Cw = W(2);
+                o.esn = fld(Cw, 4, 32);
                 uint8_t nawc = (uint8_t)(o.a_NAWC - 2);
-                if ((uint8_t)getbits(Cw + 1, 3) != nawc) o.flags |= AMPS_BURST_FLAG_WORDC_NAWC_MISMATCH;
+                if ((uint8_t)fld(Cw, 1, 3) != nawc) o.flags |= AMPS_BURST_FLAG_WORDC_NAWC_MISMATCH;
             }
         } else if (o.a_T == 1 && (o.a_NAWC > 2 || zero_order)) {
             uint8_t nawc = o.a_NAWC;
             unsigned next = 2;
             o.has_esn = o.a_S;
             if (o.a_S) {
-                const uint8_t *Cw = W(next++);
-                o.esn = getbits(Cw + 4, 32);
+                const uint64_t Cw = W(next++);
+                o.esn = fld(Cw, 4, 32);
                 nawc = (uint8_t)(o.a_NAWC - 2);
-                if ((uint8_t)getbits(Cw + 1, 3) != nawc) o.flags |= AMPS_BURST_FLAG_WORDC_NAWC_MISMATCH;
+                if ((uint8_t)fld(Cw, 1, 3) != nawc) o.flags |= AMPS_BURST_FLAG_WORDC_NAWC_MISMATCH;
             }
             if (nawc < 1 || nawc > 4) o.msg_class = AMPS_MSG_BAD_NAWC;
             else {
                 o.msg_class = AMPS_MSG_ORIGINATION;
                 int dl = 0;
                 for (; nawc > 0; nawc--) {
-                    unsigned digs = getbits(W(next++) + 4, 32);
+                    unsigned digs = fld(W(next++), 4, 32);
                     for (int i = 0; i < 8; i++) {       // recc_word_called::digits(), amps_packet.h:211-273
                         unsigned v = (digs >> 28) & 0xf;
                         if (v == 0) break;
