@@ -56,6 +56,7 @@ struct amps_recc {
     uint64_t *gring = nullptr;
     uint32_t ring_words = 0;
     uint32_t max_waves = 0, max_chunks = 0, det_cap = 0;   // front-launch geometry bounds (see run_iq_device)
+    uint32_t max_waves_bits = 0;                           // the same for the bit-domain kernel (more waves fit: 72 VGPRs, 2 KB LDS)
     uint64_t *det = nullptr;
     uint32_t *detcount = nullptr;
     uint64_t *next_allowed = nullptr, *pending = nullptr;
@@ -436,6 +437,14 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { amps_recc_destroy(h); return -ENODEV; }
         h->max_waves = (uint32_t)prop.multiProcessorCount * 4u * (uint32_t)front_blocks_per_cu_for(h->sps);   // exactly one resident round
+        {
+            int nb = 0;
+            hipError_t e = cfg->sync_tolerance ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, recc_front_kernel<3, 1, true, true>, 256, 0)
+                                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, recc_front_kernel<3, 1, true, false>, 256, 0);
+            if (e != hipSuccess || nb < 1) nb = 4;
+            if (nb > 8) nb = 8;                                  // max_chunks below assumes at most 32 waves per CU
+            h->max_waves_bits = (uint32_t)prop.multiProcessorCount * 4u * (uint32_t)nb;
+        }
         const uint64_t max_tiles = (maxs + 63 + TILE - 1) / TILE;
         const uint64_t max_span = std::max<uint64_t>(MIN_SPAN, (C * max_tiles + h->max_waves - 1) / h->max_waves);
         h->max_chunks = (uint32_t)(prop.multiProcessorCount * 32u / C + 3);   // bound for any occupancy
@@ -611,7 +620,7 @@ int run_bits_device(amps_recc *h, uint32_t P)
     hipStream_t s = h->stream;
     const uint32_t Tc = (P + TILE - 1) / TILE;
     const uint64_t G = (uint64_t)h->C * Tc;
-    uint32_t nwaves = (uint32_t)std::min<uint64_t>(h->max_waves, (G + MIN_SPAN - 1) / MIN_SPAN);
+    uint32_t nwaves = (uint32_t)std::min<uint64_t>(h->max_waves_bits, (G + MIN_SPAN - 1) / MIN_SPAN);
     if (nwaves == 0) nwaves = 1;
     const uint32_t span = (uint32_t)((G + nwaves - 1) / nwaves);
     if ((uint64_t)(Tc + span - 1) / span + 1 > h->max_chunks) return -E2BIG;

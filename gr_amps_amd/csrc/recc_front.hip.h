@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc
     constexpr int H = SPS - 1;                  // boxcar history
     constexpr int D = AMPS_DEDUP_SYMBOLS * SPS; // dedup / run window in samples (<= 32)
     static_assert(H <= DHIST, "history prefix too small");
-    __shared__ float    s_d_all[4][2 * DBUF];
+    __shared__ float    s_d_all[4][BITS ? 8 : 2 * DBUF];   // demod buffers: not used in the bit domain (keeps its LDS at 2 KB)
     __shared__ uint32_t s_g_all[4][GW32 + 2];   // [GW32] mirrors [0] so a tap can always read dwords qd, qd+1
     __shared__ uint32_t s_m_all[4][GW32];
 
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc
     s_g[lane] = ~0u;
     if (lane < 2) s_g[GW32 + lane] = ~0u;
     s_m[lane] = 0u;
-    for (int i = lane; i < 2 * DBUF; i += 64) s_d[i] = 0.f;
+    if constexpr (!BITS) for (int i = lane; i < 2 * DBUF; i += 64) s_d[i] = 0.f;
 
     float4 cur[4], nxt[DEPTH][4];                // tile k in use, tiles k+1..k+DEPTH in flight (DEPTH x 4 KiB per wave)
     float last_x = 0.f, last_y = 0.f;            // last sample of the previous tile (wave-uniform)
