@@ -90,8 +90,8 @@ __device__ __forceinline__ cf2 mul_mi(cf2 a) { return (cf2){ a.y, -a.x }; }   //
 //   pass 2 (radix 16): wave w reads frame w of A entirely, writes it back in place   | barrier
 //   pass 3 (radix 4): A -> C, all four frames                           | barrier
 //   pass 4 (radix 4): C -> registers (bins t, t+256, t+512, t+768 of every frame)
-// = 3 barriers per 4 frames.  The first version ran five radix-4 passes per frame with 4 barriers EACH; with the
-// barriers compiled out that kernel ran 20 % faster (0.854 -> 0.687 ms), i.e. a fifth of the time was barrier skew.
+// = 3 barriers per 4 frames.  The first version ran five radix-4 passes per frame with 4 barriers EACH (0.85 ms -> 0.69 with
+// this pipeline; with the barriers compiled out, timing only, the current kernel runs 8 % faster, the old one 20 %).
 // Frame buffers are padded by one element per 16 (cpad) so that the radix-16 write-back (stride 16 elements between
 // lanes) does not land on four banks.
 constexpr int CHZ_BATCH = 4;
