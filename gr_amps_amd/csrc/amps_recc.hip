@@ -74,6 +74,7 @@ struct amps_recc {
     hipEvent_t drain_event = nullptr;
     float2 *stage_iq = nullptr;       // device staging for host-resident IQ
     size_t stage_iq_samples = 0;
+    StageFence stage_iq_fence;
 
     // ---- channelizer seam ----
     ChannelizerState chz;
@@ -472,6 +473,7 @@ void amps_recc_destroy(amps_recc_t *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     collect_spans(h);
+    h->stage_iq_fence.destroy();
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
     h->event_pool.clear();
     void *bufs[] = { h->carry[0], h->carry[1], h->gring, h->det, h->detcount, h->next_allowed, h->pending, h->capq,
@@ -598,6 +600,7 @@ int amps_recc_push_iq(amps_recc_t *h, const float *iq, size_t ld, size_t nsamp, 
     const float2 *d = (const float2 *)iq;
     uint64_t dld = ld;
     if (mem == AMPS_MEM_HOST) {
+        if (int rc = h->stage_iq_fence.wait()) return rc;         // the previous push may still be reading the staging buffer
         if (h->stage_iq_samples < (size_t)h->C * h->cfg.max_samples_per_push) {
             if (h->stage_iq) (void)hipFree(h->stage_iq);
             h->stage_iq = nullptr; h->stage_iq_samples = 0;
@@ -609,7 +612,9 @@ int amps_recc_push_iq(amps_recc_t *h, const float *iq, size_t ld, size_t nsamp, 
                                  h->C, hipMemcpyHostToDevice, h->stream));
         d = h->stage_iq;
     }
-    return run_iq_device(h, d, dld, (uint32_t)nsamp);
+    int rc = run_iq_device(h, d, dld, (uint32_t)nsamp);
+    if (!rc && mem == AMPS_MEM_HOST) rc = h->stage_iq_fence.arm(h->stream);
+    return rc;
 }
 
 namespace {

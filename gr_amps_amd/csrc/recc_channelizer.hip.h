@@ -39,6 +39,28 @@
 
 namespace amps {
 
+// Guard of a device staging buffer for host-resident input.  A staged copy from pageable host memory is NOT ordered
+// after earlier kernels of a non-blocking stream, so back-to-back pushes without a drain in between could overwrite the
+// buffer while the previous push's kernels were still reading it (found by scripts/fuzz_parity.py: intermittent wrong
+// slicer bits near push boundaries).  wait() before refilling the buffer, arm() after enqueueing its consumers.
+struct StageFence {
+    hipEvent_t ev = nullptr;
+    bool armed = false;
+    int wait()
+    {
+        if (armed) { if (hipEventSynchronize(ev) != hipSuccess) return -EIO; armed = false; }
+        return 0;
+    }
+    int arm(hipStream_t s)
+    {
+        if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return -ENOMEM;
+        if (hipEventRecord(ev, s) != hipSuccess) return -EIO;
+        armed = true;
+        return 0;
+    }
+    void destroy() { if (ev) (void)hipEventDestroy(ev); ev = nullptr; armed = false; }
+};
+
 constexpr int CHZ_M = 1024;          // branches = FFT size
 constexpr int CHZ_D = 512;           // input samples per frame (2x oversampled)
 constexpr int CHZ_GROUP = 8;         // frames buffered in registers per output store (64-byte runs)
@@ -472,6 +494,7 @@ struct ChannelizerState {
     uint64_t ld = 0;
     float2 *stage = nullptr;        // device staging for host-resident wideband input
     size_t stage_samples = 0;
+    StageFence stage_fence;
 };
 
 inline double bessel_i0(double x)
@@ -520,6 +543,7 @@ inline int channelizer_reset(ChannelizerState &z, hipStream_t s)
 
 inline void channelizer_destroy(ChannelizerState &z)
 {
+    z.stage_fence.destroy();
     void *bufs[] = { z.taps, z.carry[0], z.carry[1], z.out, z.stage };
     for (void *p : bufs) if (p) (void)hipFree(p);
     z = ChannelizerState();
@@ -563,6 +587,7 @@ inline int channelizer_run(ChannelizerState &z, const float2 *iq, size_t nsamp, 
     if (!z.enabled) return -ENOSYS;
     const float2 *d = iq;
     if (mem == AMPS_MEM_HOST) {
+        if (int rc = z.stage_fence.wait()) return rc;             // the previous push may still be reading the staging buffer
         if (z.stage_samples < nsamp) {
             if (z.stage) (void)hipFree(z.stage);
             z.stage = nullptr; z.stage_samples = 0;
@@ -605,6 +630,7 @@ inline int channelizer_run(ChannelizerState &z, const float2 *iq, size_t nsamp, 
     hipLaunchKernelGGL(chz_carry_kernel, dim3((hist + new_left + 255) / 256), dim3(256), 0, s, d, z.carry[z.carry_cur],
                        z.carry[z.carry_cur ^ 1], z.carry_len, (uint32_t)nsamp, hist, consumed, hist + new_left);
     if (hipGetLastError() != hipSuccess) return -EIO;
+    if (mem == AMPS_MEM_HOST) { if (int rc = z.stage_fence.arm(s)) return rc; }
     z.carry_cur ^= 1;
     z.carry_len = hist + new_left;
     z.frames_done += nframes;

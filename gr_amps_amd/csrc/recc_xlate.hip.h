@@ -122,6 +122,7 @@ struct XlateState {
     float2 *out = nullptr;
     float2 *stage = nullptr;
     size_t stage_samples = 0;
+    StageFence stage_fence;
     std::vector<float> taps_host;
 };
 
@@ -153,6 +154,7 @@ inline void xlate_destroy(XlateState &x)
     if (x.carry[1]) (void)hipFree(x.carry[1]);
     if (x.out) (void)hipFree(x.out);
     if (x.stage) (void)hipFree(x.stage);
+    x.stage_fence.destroy();
     x = XlateState{};
 }
 
@@ -199,6 +201,7 @@ inline int xlate_run(XlateState &x, const float2 *iq, uint64_t ld, size_t nsamp,
     if (nsamp > (size_t)x.D * x.max_out) return -E2BIG;
     const float2 *d = iq;
     if (mem == AMPS_MEM_HOST) {
+        if (int rc = x.stage_fence.wait()) return rc;             // the previous push may still be reading the staging buffer
         const size_t need = (size_t)x.C * x.D * x.max_out;
         if (x.stage_samples < need) {
             if (x.stage) (void)hipFree(x.stage);
@@ -230,6 +233,7 @@ inline int xlate_run(XlateState &x, const float2 *iq, uint64_t ld, size_t nsamp,
     hipLaunchKernelGGL(xlate_carry_kernel, dim3((new_len + 255) / 256, x.C), dim3(256), 0, s, d, ld, x.carry[x.cur], x.carry[x.cur ^ 1],
                        x.carry_cap, x.carry_len, consumed, new_len);
     if (hipGetLastError() != hipSuccess) return -EIO;
+    if (mem == AMPS_MEM_HOST) { if (int rc = x.stage_fence.arm(s)) return rc; }
     x.cur ^= 1; x.carry_len = new_len; x.n_abs += consumed;
     *nout = (uint32_t)n_out;
     return 0;
