@@ -608,8 +608,11 @@ int amps_recc_push_iq(amps_recc_t *h, const float *iq, size_t ld, size_t nsamp, 
             h->stage_iq_samples = (size_t)h->C * h->cfg.max_samples_per_push;
         }
         dld = nsamp;
-        HIP_TRY(hipMemcpy2DAsync(h->stage_iq, dld * sizeof(float2), iq, ld * sizeof(float2), nsamp * sizeof(float2),
-                                 h->C, hipMemcpyHostToDevice, h->stream));
+        // synchronous on purpose: an async copy from pageable memory can return before the source has been read (the
+        // fuzzer caught blocks freed right after the call being copied late); the fence above has already made sure
+        // nobody is reading the staging buffer, and the kernels below are enqueued after the copy has completed
+        HIP_TRY(hipMemcpy2D(h->stage_iq, dld * sizeof(float2), iq, ld * sizeof(float2), nsamp * sizeof(float2),
+                            h->C, hipMemcpyHostToDevice));
         d = h->stage_iq;
     }
     int rc = run_iq_device(h, d, dld, (uint32_t)nsamp);

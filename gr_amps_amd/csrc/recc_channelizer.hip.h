@@ -39,10 +39,11 @@
 
 namespace amps {
 
-// Guard of a device staging buffer for host-resident input.  A staged copy from pageable host memory is NOT ordered
-// after earlier kernels of a non-blocking stream, so back-to-back pushes without a drain in between could overwrite the
-// buffer while the previous push's kernels were still reading it (found by scripts/fuzz_parity.py: intermittent wrong
-// slicer bits near push boundaries).  wait() before refilling the buffer, arm() after enqueueing its consumers.
+// Guard of a device staging buffer for host-resident input.  Copies from pageable host memory are neither ordered after
+// earlier kernels of a non-blocking stream nor guaranteed to have read their source when an Async call returns, so
+// back-to-back pushes without a drain in between corrupted samples (found by scripts/fuzz_parity.py: intermittent wrong
+// slicer bits).  Host pushes therefore: wait() until the previous push's kernels have released the staging buffer,
+// copy synchronously, enqueue the kernels, arm().
 struct StageFence {
     hipEvent_t ev = nullptr;
     bool armed = false;
@@ -594,7 +595,8 @@ inline int channelizer_run(ChannelizerState &z, const float2 *iq, size_t nsamp, 
             if (hipMalloc((void **)&z.stage, sizeof(float2) * nsamp) != hipSuccess) return -ENOMEM;
             z.stage_samples = nsamp;
         }
-        if (hipMemcpyAsync(z.stage, iq, sizeof(float2) * nsamp, hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
+        // synchronous: the caller may reuse its buffer as soon as the push returns (see amps_recc_push_iq)
+        if (hipMemcpy(z.stage, iq, sizeof(float2) * nsamp, hipMemcpyHostToDevice) != hipSuccess) return -EIO;
         d = z.stage;
     }
     const uint32_t hist = chz_hist(z.P);

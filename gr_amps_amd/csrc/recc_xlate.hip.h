@@ -209,8 +209,8 @@ inline int xlate_run(XlateState &x, const float2 *iq, uint64_t ld, size_t nsamp,
             if (hipMalloc((void **)&x.stage, sizeof(float2) * need) != hipSuccess) return -ENOMEM;
             x.stage_samples = need;
         }
-        if (hipMemcpy2DAsync(x.stage, nsamp * sizeof(float2), iq, ld * sizeof(float2), nsamp * sizeof(float2), x.C,
-                             hipMemcpyHostToDevice, s) != hipSuccess) return -EIO;
+        if (hipMemcpy2D(x.stage, nsamp * sizeof(float2), iq, ld * sizeof(float2), nsamp * sizeof(float2), x.C,
+                        hipMemcpyHostToDevice) != hipSuccess) return -EIO;       // synchronous: see amps_recc_push_iq
         d = x.stage; ld = nsamp;
     }
     const uint64_t avail = (uint64_t)(x.carry_len - x.hist) + nsamp;

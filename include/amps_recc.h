@@ -183,12 +183,11 @@ int amps_recc_decode_bursts(amps_recc_t *h, const uint8_t *bursts, size_t nburst
 /* (ii) fused seam: interleaved fc32 IQ, channel-major: sample i of channel c at iq[2*(c*ld + i)].
  * Enqueues the fused demod->sync->capture->decode kernels on the handle's stream and returns
  * without synchronising; results accumulate on the device until amps_recc_drain().
- * Ownership: a pageable HOST buffer is staged by the HIP runtime before the call returns and may be
- * reused at once (the library fences its device staging buffer between pushes).  A DEVICE buffer --
- * and a page-locked host buffer (hipHostMalloc / hipHostRegister), whose copy is truly asynchronous --
- * is read by work still in flight: it must stay valid and unmodified until a drain (or drain_end) that
- * covers this push has returned, or the caller has synchronised the handle's stream.  The same holds
- * for push_wideband / push_raw. */
+ * Ownership: a HOST buffer has been copied to the device when the call returns (synchronous copy into a
+ * fenced staging buffer) and may be reused at once.  A DEVICE buffer is read in place by the enqueued
+ * kernels: it must stay valid and unmodified until a drain (or drain_end) that covers this push has
+ * returned, or the caller has synchronised the handle's stream.  The same holds for push_wideband /
+ * push_raw. */
 int amps_recc_push_iq(amps_recc_t *h, const float *iq, size_t ld, size_t nsamp, int mem);
 
 /* channelizer seam: one wideband interleaved fc32 stream (fs = M * 30 kHz) -> polyphase

@@ -5,7 +5,10 @@ host- or device-resident blocks.  Used by tests/test_gpu_fuzz.py and scripts/fuz
 
 History: the first campaign (150 cases) failed 48 times -- host-resident blocks pushed back to back without a drain in
 between could be overwritten in the device staging buffer while the previous push's kernels were still reading it (a
-staged copy from pageable memory is not ordered after earlier kernels of a non-blocking stream).  Fixed with StageFence."""
+staged copy from pageable memory is not ordered after earlier kernels of a non-blocking stream): fixed with StageFence.
+A second campaign failed 2 of 1500 host-block cases: hipMemcpy2DAsync from pageable memory had not read its source
+when it returned and the test freed the block: fixed with a synchronous staging copy (keep_host=True keeps the blocks
+alive, which is how the cause was isolated)."""
 import numpy as np
 
 import oracle
@@ -39,7 +42,7 @@ def build_case(case, seed0):
     return rng, dict(sps=sps, C=C, tol=tol, snr=round(snr, 1), N=N), iq
 
 
-def run_case(case, seed0, resident=False):
+def run_case(case, seed0, resident=False, keep_host=False):
     """returns (ok, info)"""
     rng, info, iq = build_case(case, seed0)
     sps, C, tol, N = info["sps"], info["C"], info["tol"], info["N"]
@@ -54,6 +57,8 @@ def run_case(case, seed0, resident=False):
             if resident:           # the caller owns device blocks until the results are drained
                 blk = torch.from_numpy(blk).to("cuda:0")
                 torch.cuda.synchronize()
+                keep.append(blk)
+            if keep_host:
                 keep.append(blk)
             r.push_iq(blk)
             off += b
