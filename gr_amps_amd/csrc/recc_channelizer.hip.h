@@ -377,19 +377,22 @@ __global__ __launch_bounds__(256) void chz_pfb_fft_kernel(ChzArgs a)
 // register that is stored to the channel's bit ring every 32 frames.  The arithmetic is the same as
 // recc_front_kernel's on the channel-major intermediate, so both forms produce identical bits.
 template <int PAR, bool FOUR = true>
-__device__ __forceinline__ void chz_bins(const cf2 (&y)[4], cf2 (&prev)[4], float (&d1)[4], float (&d2)[4], uint32_t (&gw)[4])
+__device__ __forceinline__ void chz_bins(const cf2 (&y)[4], cf2 (&prev)[4], f2 (&d1)[2], f2 (&d2)[2], uint32_t (&gw)[4])
 {
-    f2 da, db;
-    if constexpr (FOUR) fm_phase_four(y, prev, da, db);           // two chains in lock step (same bits, fewer stalls, more registers)
-    else { da = fm_phase_two(y[0], prev[0], y[1], prev[1]); db = fm_phase_two(y[2], prev[2], y[3], prev[3]); }
-    const float d[4] = { da.x, da.y, db.x, db.y };
+    f2 d[2];
+    if constexpr (FOUR) fm_phase_four(y, prev, d[0], d[1]);       // two chains in lock step (same bits, fewer stalls, more registers)
+    else { d[0] = fm_phase_two(y[0], prev[0], y[1], prev[1]); d[1] = fm_phase_two(y[2], prev[2], y[3], prev[3]); }
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int h = 0; h < 2; h++) {                                 // bins (0,1) and (2,3): the boxcar adds are packed per pair
         // window [n-2, n]: n even -> (d[n-2] + d[n-1]) + d[n];  n odd -> d[n-2] + (d[n-1] + d[n])
-        const float s = PAR == 0 ? (d2[j] + d1[j]) + d[j] : d2[j] + (d1[j] + d[j]);
-        gw[j] = (gw[j] >> 1) | (s >= 0.0f ? 0x80000000u : 0u);
-        d2[j] = d1[j]; d1[j] = d[j]; prev[j] = y[j];
+        const f2 s = PAR == 0 ? (d2[h] + d1[h]) + d[h] : d2[h] + (d1[h] + d[h]);
+        // gw = (gw >> 1) | (s >= 0) << 31 as one v_alignbit per bin
+        gw[2 * h] = __builtin_amdgcn_alignbit(s.x >= 0.0f ? 1u : 0u, gw[2 * h], 1);
+        gw[2 * h + 1] = __builtin_amdgcn_alignbit(s.y >= 0.0f ? 1u : 0u, gw[2 * h + 1], 1);
+        d2[h] = d1[h]; d1[h] = d[h];
     }
+#pragma unroll
+    for (int j = 0; j < 4; j++) prev[j] = y[j];
 }
 
 // P = 8 is held to 256 VGPRs = two waves per SIMD (left alone the allocator takes 258 and halves the occupancy;
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(256, P <= 8 ? 2 : 1) void chz_fused_kernel(ChzArgs 
         }
     }
     cf2 prev[4] = {};
-    float d1[4] = {}, d2[4] = {};
+    f2 d1[2] = {}, d2[2] = {};                                    // the last two demod floats of bins (0,1) and (2,3)
     uint32_t gw[4] = { ~0u, ~0u, ~0u, ~0u };
     const uint64_t mask32 = 2ull * a.ring_words - 1;
 
