@@ -100,7 +100,7 @@ __device__ __forceinline__ cf2 mul_mi(cf2 a) { return (cf2){ a.y, -a.x }; }   //
 
 // History on MI355X (1 GiB of wideband per launch, fused kernel ms): LDS sample ring 1.49 -> register delay lines 1.26 ->
 // fused discriminator 1.02 -> packed complex multiply 0.90 -> lock-step 4-way discriminator 0.87 -> two-frame prefetch 0.83
-// -> four-frame batches with a radix-16 pass 0.69 -> per-batch branch-free input path 0.67.
+// -> four-frame batches with a radix-16 pass 0.69 -> per-batch branch-free input path 0.67 -> packed boxcar adds 0.64.
 // Measured and rejected (kernel ms at the time): baseline 1.24; XOR-swizzled exchange
 // buffers 1.36 (33 % of LDS cycles are bank conflicts, but the kernel is latency- not LDS-bound and the index math
 // sits on the critical path); padded buffers 2.0 (LDS over 80 KiB -> one workgroup per CU, LDS-ring version);
