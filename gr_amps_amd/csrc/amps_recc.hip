@@ -18,6 +18,7 @@
 #include "recc_symbols.hip.h"
 #include "recc_channelizer.hip.h"
 #include "recc_xlate.hip.h"
+#include "recc_bits.hip.h"
 
 static_assert(sizeof(amps_recc_burst_t) == AMPS_RECC_BURST_BYTES, "record layout is part of the ABI");
 static_assert(sizeof(amps_recc_burst_t) % 8 == 0, "records are copied as dwords");
@@ -219,6 +220,13 @@ int reset_state(amps_recc *h)
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(s));
     return 0;
+}
+
+bool bits_kernel_is_front()   // AMPS_RECC_BITS_KERNEL=front: search the bit ring with recc_front_kernel<3,1,BITS> (cross-check)
+{
+    static int v = -1;
+    if (v < 0) { const char *e = std::getenv("AMPS_RECC_BITS_KERNEL"); v = (e && e[0] == 'f') ? 1 : 0; }
+    return v == 1;
 }
 
 int front_depth()   // tiles in flight per wave; AMPS_RECC_DEPTH overrides for experiments
@@ -441,7 +449,8 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
         {
             int nb = 0;
             hipError_t e = cfg->sync_tolerance ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, recc_front_kernel<3, 1, true, true>, 256, 0)
-                                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, recc_front_kernel<3, 1, true, false>, 256, 0);
+                           : bits_kernel_is_front() ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, recc_front_kernel<3, 1, true, false>, 256, 0)
+                                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, recc_bits_kernel<3>, 256, 0);
             if (e != hipSuccess || nb < 1) nb = 4;
             if (nb > 8) nb = 8;                                  // max_chunks below assumes at most 32 waves per CU
             h->max_waves_bits = (uint32_t)prop.multiProcessorCount * 4u * (uint32_t)nb;
@@ -639,8 +648,11 @@ int run_bits_device(amps_recc *h, uint32_t P)
     fa.tol = h->cfg.sync_tolerance;
     {
         SpanGuard g(h, T_FRONT, P);
+        // exact match: the dedicated bit-domain kernel; tolerant sync: the bit-domain mode of the streaming kernel
+        // (AMPS_RECC_BITS_KERNEL=front selects the latter for the exact match too: the two must agree)
         if (fa.tol) hipLaunchKernelGGL((recc_front_kernel<3, 1, true, true>), dim3((nwaves + 3) / 4), dim3(256), 0, s, fa);
-        else hipLaunchKernelGGL((recc_front_kernel<3, 1, true>), dim3((nwaves + 3) / 4), dim3(256), 0, s, fa);
+        else if (bits_kernel_is_front()) hipLaunchKernelGGL((recc_front_kernel<3, 1, true>), dim3((nwaves + 3) / 4), dim3(256), 0, s, fa);
+        else hipLaunchKernelGGL(recc_bits_kernel<3>, dim3((nwaves + 3) / 4), dim3(256), 0, s, fa);
     }
     HIP_TRY(hipMemsetAsync(h->capq_count, 0, sizeof(uint32_t), s));
     ResolveArgs ra{};
