@@ -202,8 +202,7 @@ int reset_state(amps_recc *h)
         HIP_TRY(hipMemsetAsync(h->capq_count, 0, sizeof(uint32_t), s));
     }
     for (int b = 0; b < 2; b++) {
-        HIP_TRY(hipMemsetAsync(h->nrecords_buf[b], 0, sizeof(uint32_t), s));
-        HIP_TRY(hipMemsetAsync(h->status_buf[b], 0, sizeof(uint32_t), s));
+        HIP_TRY(hipMemsetAsync(h->nrecords_buf[b], 0, 2 * sizeof(uint32_t), s));
     }
     h->open_buf = -1;
     select_record_list(h, 0);
@@ -421,7 +420,10 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
     int rc = 0;
     const size_t C = h->C;
     // results + symbol seam (always present)
-    for (int b = 0; b < 2; b++) { rc |= dev_alloc(&h->nrecords_buf[b], 1); rc |= dev_alloc(&h->status_buf[b], 1); }
+    for (int b = 0; b < 2; b++) {   // {nrecords, status} of a list are adjacent: one 8-byte copy / memset serves both
+        rc |= dev_alloc(&h->nrecords_buf[b], 2);
+        h->status_buf[b] = h->nrecords_buf[b] ? h->nrecords_buf[b] + 1 : nullptr;
+    }
     rc |= dev_alloc(&h->symbuf, C * AMPS_RECC_SYMBUF);
     rc |= dev_alloc(&h->sym_len, C);
     rc |= dev_alloc(&h->sym_cur, C);
@@ -486,7 +488,7 @@ void amps_recc_destroy(amps_recc_t *h)
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
     h->event_pool.clear();
     void *bufs[] = { h->carry[0], h->carry[1], h->gring, h->det, h->detcount, h->next_allowed, h->pending, h->capq,
-                     h->capq_count, h->nrecords_buf[0], h->nrecords_buf[1], h->status_buf[0], h->status_buf[1], h->stage_iq, h->symbuf, h->sym_len, h->sym_cur,
+                     h->capq_count, h->nrecords_buf[0], h->nrecords_buf[1], h->stage_iq, h->symbuf, h->sym_len, h->sym_cur,
                      h->sym_stage, h->bursts_dev, h->burst_chan_dev, h->nbursts_dev, h->dec_out_dev, h->dec_in_dev,
                      h->dec_chan_dev, h->dbg_d, h->dbg_S };
     for (void *p : bufs) if (p) (void)hipFree(p);
@@ -770,8 +772,7 @@ int amps_recc_drain_begin(amps_recc_t *h)
     hipStream_t s = h->stream;
     const int b = h->cur_buf;
     uint32_t *hdr = h->hdr_host + 2 * b;
-    HIP_TRY(hipMemcpyAsync(&hdr[0], h->nrecords_buf[b], sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&hdr[1], h->status_buf[b], sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&hdr[0], h->nrecords_buf[b], 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipEventRecord(h->drain_event, s));
     h->open_buf = b;
     select_record_list(h, b ^ 1);           // later pushes append to the other list
@@ -808,8 +809,7 @@ int amps_recc_drain_end(amps_recc_t *h, amps_recc_burst_t *out, size_t cap, size
         if (n > cap) rc = -ENOSPC;
     }
     // the list is empty again before it becomes current (stream order: these precede every later push into it)
-    HIP_TRY(hipMemsetAsync(h->nrecords_buf[b], 0, sizeof(uint32_t), s));
-    HIP_TRY(hipMemsetAsync(h->status_buf[b], 0, sizeof(uint32_t), s));
+    HIP_TRY(hipMemsetAsync(h->nrecords_buf[b], 0, 2 * sizeof(uint32_t), s));
     h->open_buf = -1;
     return rc;
 }
