@@ -14,7 +14,7 @@ rocprofv3 --output-format csv --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LD
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $SHORT > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $SHORT > $OUT/pmc_write.log 2>&1
 find $OUT -type f ! -name "*.csv" ! -name "*.log" -delete
-for k in chz_fused "recc_front_kernel<10" "recc_front_kernel<3"; do echo "== $k"; python $R/scripts/pmc_summary.py $OUT "$k"; done | tee $OUT/pmc_kernels.txt
+for k in chz_fused "recc_front_kernel<10" "recc_bits_kernel"; do echo "== $k"; python $R/scripts/pmc_summary.py $OUT "$k"; done | tee $OUT/pmc_kernels.txt
 # keep the summaries, drop the raw per-dispatch tables (tens of MB: gpurun merges at most 64 MiB back)
 find $OUT -name "*counter_collection.csv" -delete
 find $OUT -name "*kernel_trace.csv" -delete
