@@ -135,6 +135,21 @@ def cpu_baseline(iq_base, sps, budget_s):
     }
 
 
+def profile_entry(key):
+    """the PMC-derived entry of this workload in profiles/rNN/traffic.json (newest round), or None"""
+    pdir = os.path.join(ROOT, "profiles")
+    if not os.path.isdir(pdir):
+        return None
+    for tag in sorted(os.listdir(pdir), reverse=True):
+        tj = os.path.join(pdir, tag, "traffic.json")
+        if os.path.exists(tj):
+            t = json.load(open(tj))
+            for e in (t if isinstance(t, list) else [t]):
+                if e.get("key") == key:
+                    return e
+    return None
+
+
 def traffic_from_profiles(key):
     """HBM bytes per launch from the PMC passes of the same command (profiles/rNN/traffic.json)."""
     pdir = os.path.join(ROOT, "profiles")
@@ -266,6 +281,7 @@ def run_workload(name, a, torch, dev, dist, rank, world, local):
                    "bursts_decoded_per_step_per_gpu": nrec // max(1, a.steps), "parallelism": "channels sharded x%d, no data-path collective" % world},
         "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic_from_profiles(name),
+                     "valu_issue_frac_pmc": (profile_entry(name) or {}).get("valu_issue_frac"),
                      "kernel": kname, "kernel_ms": round(kms, 4), "note": note,
                      "frac_of_measured_copy_ceiling_6290": round(ach / 6290.0, 4),
                      "other_kernels_ms_per_step": {k: round(tm_all[k] / n_all, 4) for k in ("ms_front", "ms_resolve", "ms_decode", "ms_carry", "ms_channelizer")},
