@@ -62,6 +62,7 @@ struct orc_fused {
     uint64_t pending_nc;
     uint8_t  trig[AMPS_RECC_TRIGGER_SYMS];
     int      tol;             /* accepted mismatching symbols of the 74 (0 = exact match = reference behaviour) */
+    int      majority;        /* decode captures in the product's majority mode (AMPS_RECC_FLAG_MAJORITY)       */
 };
 
 orc_fused_t *orc_fused_new(uint32_t channel, int sps)
@@ -77,6 +78,7 @@ void orc_fused_free(orc_fused_t *f)
     free(f->x); free(f->d); free(f->S); free(f->g); free(f->M); free(f);
 }
 void orc_fused_set_tolerance(orc_fused_t *f, int k) { f->tol = k < 0 ? 0 : k; }
+void orc_fused_set_majority(orc_fused_t *f, int on) { f->majority = on != 0; }
 size_t orc_fused_processed(const orc_fused_t *f) { return f->n_done; }
 const float *orc_fused_demod(const orc_fused_t *f) { return f->d; }
 const float *orc_fused_soft(const orc_fused_t *f) { return f->S; }
@@ -101,7 +103,7 @@ static void capture(orc_fused_t *f, uint64_t nc, amps_recc_burst_t *out)
 {
     uint8_t burst[AMPS_RECC_CAPTURE_SYMS];
     for (int i = 0; i < AMPS_RECC_CAPTURE_SYMS; i++) burst[i] = f->g[nc + (uint64_t)f->sps * (uint64_t)(i + 1)];
-    orc_decode_burst(burst, f->channel, nc, out);
+    orc_decode_burst_mode(burst, f->channel, nc, out, f->majority);
 }
 
 size_t orc_fused_push(orc_fused_t *f, const float *iq, size_t n, amps_recc_burst_t *out, size_t cap)

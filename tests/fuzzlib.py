@@ -22,6 +22,7 @@ def build_case(case, seed0):
     sps = int(rng.choice([3, 4, 5, 6, 8, 10, 12]))
     C = int(rng.integers(1, 5))
     tol = int(rng.choice([0, 0, 0, 1, 2, 4, 8]))
+    majority = bool(rng.integers(0, 4) == 0)
     specs, N = [], 0
     for _ in range(C):
         off, bursts = int(rng.integers(200, 5000)), []
@@ -39,17 +40,17 @@ def build_case(case, seed0):
     N = int(N)
     snr = float(rng.uniform(8, 30))
     iq = np.stack([synth.fsk_modulate(N, b, sps=sps, fs=20e3 * sps, snr_db=snr, rng=rng) for b in specs])
-    return rng, dict(sps=sps, C=C, tol=tol, snr=round(snr, 1), N=N), iq
+    return rng, dict(sps=sps, C=C, tol=tol, majority=majority, snr=round(snr, 1), N=N), iq
 
 
 def run_case(case, seed0, resident=False, keep_host=False):
     """returns (ok, info)"""
     rng, info, iq = build_case(case, seed0)
     sps, C, tol, N = info["sps"], info["C"], info["tol"], info["N"]
-    want = oracle.fused_push_all(iq, sps=sps, tolerance=tol)
+    want = oracle.fused_push_all(iq, sps=sps, tolerance=tol, majority=info["majority"])
     if resident:
         import torch
-    with capi.Recc(n_channels=C, sps=sps, max_samples=N, max_bursts=256, sync_tolerance=tol) as r:
+    with capi.Recc(n_channels=C, sps=sps, max_samples=N, max_bursts=256, sync_tolerance=tol, majority=info["majority"]) as r:
         off, recs, pipelined, open_, keep = 0, [], bool(rng.integers(0, 2)), False, []
         while off < N:
             b = int(min(N - off, rng.integers(1, max(2, N // 2))))
