@@ -82,7 +82,7 @@ EXPORTS = (
     "amps_recc_get_timing", "amps_recc_reply_words", "amps_recc_debug_channelize",
     "amps_bch_encode_words", "amps_bch_decode_words",
     "amps_recc_set_xlate", "amps_recc_push_raw", "amps_recc_debug_xlate", "amps_recc_set_timing",
-    "amps_recc_drain_begin", "amps_recc_drain_end",
+    "amps_recc_drain_begin", "amps_recc_drain_end", "amps_recc_set_origin",
 )
 
 _lib = None
@@ -113,6 +113,7 @@ def load():
     L.amps_recc_destroy.argtypes = [vp]
     L.amps_recc_destroy.restype = None
     L.amps_recc_reset.argtypes = [vp]
+    L.amps_recc_set_origin.argtypes = [vp, C.c_uint64]
     L.amps_recc_push_symbols.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.amps_recc_decode_bursts.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, vp]
     L.amps_recc_push_iq.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int]
@@ -340,6 +341,12 @@ class Recc:
         if rc:
             raise AmpsError(rc, "amps_recc_drain")
         return out[:nout.value].copy() if copy else out[:nout.value]
+
+    def set_origin(self, first_sample):
+        """absolute index of the first sample pushed after create / reset (multiple of 64)"""
+        rc = load().amps_recc_set_origin(self._h, first_sample)
+        if rc:
+            raise AmpsError(rc, "amps_recc_set_origin")
 
     def drain_begin(self):
         """Close the current record list without waiting; pushes issued after this append to a second list."""

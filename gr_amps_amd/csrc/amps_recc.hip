@@ -54,6 +54,7 @@ struct amps_recc {
     int carry_cur = 0;
     uint64_t n_done = 0;
     uint32_t r_prev = 0;
+    bool origin_locked = false;       // a push has happened since the last reset
     uint64_t *gring = nullptr;
     uint32_t ring_words = 0;
     uint32_t max_waves = 0, max_chunks = 0, det_cap = 0;   // front-launch geometry bounds (see run_iq_device)
@@ -212,6 +213,7 @@ int reset_state(amps_recc *h)
     HIP_TRY(hipMemsetAsync(h->nbursts_dev, 0, sizeof(uint32_t), s));
     h->carry_cur = 0;
     h->n_done = 0;
+    h->origin_locked = false;
     h->r_prev = 0;
     int rc = channelizer_reset(h->chz, s);
     if (rc) return rc;
@@ -300,6 +302,7 @@ static void launch_resolve(amps_recc *h, const ResolveArgs &ra, hipStream_t s)
 
 int run_iq_device(amps_recc *h, const float2 *iq, uint64_t ld, uint32_t nsamp)
 {
+    h->origin_locked = true;
     if (nsamp == 0) return 0;
     hipStream_t s = h->stream;
     const uint32_t avail = h->r_prev + nsamp;
@@ -397,6 +400,7 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
     if (cfg->n_channels < 1 || cfg->max_bursts < 1) return -EINVAL;
     if (cfg->max_samples_per_push && !sps_supported(cfg->samples_per_symbol)) return -EINVAL;
     if (cfg->sync_tolerance > AMPS_RECC_MAX_SYNC_TOLERANCE) return -EINVAL;
+    if (cfg->n_channels >= (1u << (64 - CAPQ_POS_BITS))) return -EINVAL;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return -ENODEV;
     int dev = cfg->device;
@@ -687,6 +691,7 @@ int amps_recc_push_wideband(amps_recc_t *h, const float *iq, size_t nsamp, int m
     if (!h->chz.enabled) return -ENOSYS;
     if (nsamp == 0) return 0;
     if (!iq) return -EINVAL;
+    h->origin_locked = true;
     HIP_TRY(hipSetDevice(h->device));
     // Fused form (default): filter bank + discriminator + boxcar + slicer in one kernel, then the bit-domain
     // correlator.  AMPS_RECC_FLAG_UNFUSED_WIDEBAND keeps the two-kernel form (channel-major intermediate in HBM).
@@ -801,7 +806,7 @@ int amps_recc_drain_end(amps_recc_t *h, amps_recc_burst_t *out, size_t cap, size
         struct Key { uint64_t k; uint32_t i; };
         std::vector<Key> keys(n);
         const amps_recc_burst_t *r = h->rec_host_buf[b];
-        for (uint32_t i = 0; i < n; i++) keys[i] = { ((uint64_t)r[i].channel << 40) | (r[i].position & ((1ull << 40) - 1)), i };
+        for (uint32_t i = 0; i < n; i++) keys[i] = { ((uint64_t)r[i].channel << CAPQ_POS_BITS) | (r[i].position & ((1ull << CAPQ_POS_BITS) - 1)), i };
         std::sort(keys.begin(), keys.end(), [](const Key &x, const Key &y) { return x.k < y.k; });
         size_t k = std::min<size_t>(n, cap);
         if (out) for (size_t i = 0; i < k; i++) std::memcpy(&out[i], &r[keys[i].i], sizeof(amps_recc_burst_t));
@@ -883,6 +888,15 @@ int amps_recc_debug_channelize(amps_recc_t *h, const float *iq, size_t nsamp, in
         HIP_TRY(hipMemcpy2DAsync(out, out_ld * sizeof(float2), chan_iq, ld * sizeof(float2), nout * sizeof(float2), h->C,
                                  hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int amps_recc_set_origin(amps_recc_t *h, uint64_t first_sample)
+{
+    if (!h || (first_sample & 63u) || first_sample >= (1ull << CAPQ_POS_BITS)) return -EINVAL;
+    if (!h->carry[0]) return -ENOSYS;
+    if (h->n_done != 0 || h->r_prev != 0 || h->origin_locked) return -EBUSY;     // only on a fresh or reset handle
+    h->n_done = first_sample;
     return 0;
 }
 

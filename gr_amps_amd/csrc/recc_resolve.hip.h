@@ -17,6 +17,9 @@
 
 namespace amps {
 
+// a queued capture packs (channel, position): 2^44 samples per channel stream (2.8 years at 200 ksps) and 2^20 channels
+constexpr int CAPQ_POS_BITS = 44;
+
 struct ResolveArgs {
     const uint64_t *det;       // [C][max_chunks][det_cap]
     const uint32_t *detcount;  // [C][max_chunks]
@@ -27,7 +30,7 @@ struct ResolveArgs {
     uint64_t *next_allowed;    // [C]
     uint64_t *pending;         // [C], ~0 = none (holds n_c)
     uint2    *capq_chan;       // unused
-    uint64_t *capq;            // [capq_cap] (channel << 40 | n_c)  -- n_c < 2^40 samples
+    uint64_t *capq;            // [capq_cap] (channel << CAPQ_POS_BITS | n_c)
     uint32_t *capq_count;      // atomic
     uint32_t capq_cap;
     uint32_t *status;          // bit 1: capture queue overflow
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(THREADS) void recc_resolve_kernel(ResolveArgs a)
             __syncthreads();
             const uint32_t base = s_base;
             for (uint32_t i = tid; i < m; i += THREADS) {
-                if (base + i < a.capq_cap) a.capq[base + i] = ((uint64_t)c << 40) | s_acc[i];
+                if (base + i < a.capq_cap) a.capq[base + i] = ((uint64_t)c << CAPQ_POS_BITS) | (s_acc[i] & ((1ull << CAPQ_POS_BITS) - 1));
                 else atomicOr(a.status, 2u);
             }
         }
@@ -172,8 +175,8 @@ __global__ __launch_bounds__(64) void recc_capture_kernel(CaptureArgs a)
     if (ncap > a.capq_cap) ncap = a.capq_cap;
     for (uint32_t q = blockIdx.x; q < ncap; q += gridDim.x) {
         const uint64_t e = a.capq[q];
-        const uint32_t c = (uint32_t)(e >> 40);
-        const uint64_t nc = e & ((1ull << 40) - 1);
+        const uint32_t c = (uint32_t)(e >> CAPQ_POS_BITS);
+        const uint64_t nc = e & ((1ull << CAPQ_POS_BITS) - 1);
         const uint64_t *ring = a.gring + (uint64_t)c * a.ring_words;
         const uint64_t w0 = (nc + a.sps) >> 6;
         const int nw = (int)(((nc + (uint64_t)a.sps * AMPS_RECC_CAPTURE_SYMS) >> 6) - w0) + 1;

@@ -125,7 +125,8 @@ typedef struct amps_recc_burst {
 
 typedef struct amps_recc_cfg {
     uint32_t struct_size;          /* sizeof(amps_recc_cfg_t), for ABI evolution                          */
-    uint32_t n_channels;           /* independent RECC instances handled per push (>=1)                   */
+    uint32_t n_channels;           /* independent RECC instances handled per push (1 .. 2^20-1); a channel's
+                                    * stream may run for 2^44 samples between resets (2.8 years at 200 ksps) */
     uint32_t samples_per_symbol;   /* IQ seam: samples per Manchester symbol (10 at 200 ksps); 2..16      */
     uint32_t max_samples_per_push; /* IQ seam: capacity per channel per push (0 = IQ seam unused)         */
     uint32_t max_bursts;           /* capacity of the device-side result list per push/drain (>=1)        */
@@ -167,6 +168,10 @@ size_t      amps_recc_burst_size(void);   /* sizeof(amps_recc_burst_t), for bind
 int  amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg);
 void amps_recc_destroy(amps_recc_t *h);
 int  amps_recc_reset(amps_recc_t *h);     /* back to the just-constructed state of every channel */
+/* Resume / offset a stream: the first sample pushed after create or reset gets this absolute index (a multiple of 64,
+ * < 2^44), so `position` of the records continues a numbering kept elsewhere (checkpoint / restart of a receiver).
+ * What precedes the origin is treated like what precedes a stream that starts at 0.  -EBUSY after the first push. */
+int  amps_recc_set_origin(amps_recc_t *h, uint64_t first_sample);
 
 /* (i) exact drop-in seam.  One call == one recc_impl::work() call on EVERY channel with
  * noutput_items = n; syms is [n_channels][ld] bytes (values 0/1).  Bursts published by this call

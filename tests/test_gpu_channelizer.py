@@ -151,3 +151,23 @@ def test_config2_64_channels_behind_the_channelizer(gpu):
     want = oracle.fused_push_all(chan, sps=3)
     assert [(int(w["channel"]), w["min"]) for w in want] == [(int(g["channel"]), g["min"]) for g in got]
     assert all(np.array_equal(a["word_raw"], b["word_raw"]) and np.array_equal(a["word_dec"], b["word_dec"]) for a, b in zip(want, got))
+
+
+def test_wideband_stream_origin(gpu):
+    """the same on the wideband seam (origin counts channel samples, i.e. channelizer frames)"""
+    first, C = 96, 832
+    n = int(0.25 * sw.FS_WIDE) // D * D
+    bursts = [(first + 7, 100000), (first + 500, 150000)]
+    x, truth = sw.make_wideband(n, bursts, seed=31)
+    outs = []
+    for origin in (0, (1 << 42) + 64 * 999):
+        with _handle(C, first, n // D + 72) as r:
+            if origin:
+                r.set_origin(origin)
+            r.push_wideband(x[: n // 3])
+            r.push_wideband(x[n // 3:])
+            r.push_wideband(np.zeros(64 * D, np.complex64))
+            g = r.drain()
+        g["position"] -= np.uint64(origin)
+        outs.append(g)
+    assert len(outs[0]) == len(bursts) and outs[0].tobytes() == outs[1].tobytes()

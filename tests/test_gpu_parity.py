@@ -496,3 +496,28 @@ def test_every_supported_sample_rate_matches_the_cpu_model(gpu, sps):
     got = np.concatenate(recs)
     got = got[np.lexsort((got["position"], got["channel"]))]
     assert got.tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("origin", [64, (1 << 40) - 64 * 300, (1 << 43) + 64 * 12345])
+def test_stream_origin_shifts_positions_only(gpu, origin):
+    """amps_recc_set_origin: a receiver restarted at absolute sample `origin` reports the same bursts with `position` shifted
+    by it -- also across 2^40 (the width the capture queue used to give a position) and with bursts straddling pushes."""
+    C, N = 3, 4 * 40000
+    iq, truth = _channels(C, N, 1500, nb=3)
+    want = oracle.fused_push_all(iq)
+    assert len(want) == sum(len(t) for t in truth)
+    with capi.Recc(n_channels=C, sps=10, max_samples=N, max_bursts=64) as r:
+        r.set_origin(origin)
+        for part in np.array_split(iq, 4, axis=1):
+            r.push_iq(np.ascontiguousarray(part))
+        got = r.drain()
+        with pytest.raises(capi.AmpsError):
+            r.set_origin(0)                                   # not after a push
+        r.reset()
+        r.set_origin(128)
+    with capi.Recc(n_channels=C, sps=10, max_samples=N, max_bursts=64) as r:
+        with pytest.raises(capi.AmpsError):
+            r.set_origin(origin + 1)                          # multiple of 64
+    shifted = got.copy()
+    shifted["position"] -= np.uint64(origin)
+    assert shifted.tobytes() == want.tobytes()
