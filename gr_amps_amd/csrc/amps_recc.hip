@@ -454,9 +454,13 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
         h->max_waves = (uint32_t)prop.multiProcessorCount * 4u * (uint32_t)front_blocks_per_cu_for(h->sps);   // exactly one resident round
         {
             int nb = 0;
-            hipError_t e = cfg->sync_tolerance ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, recc_front_kernel<3, 1, true, true>, 256, 0)
-                           : bits_kernel_is_front() ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, recc_front_kernel<3, 1, true, false>, 256, 0)
-                                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, recc_bits_kernel<3>, 256, 0);
+            hipError_t e;
+            if (bits_kernel_is_front())
+                e = cfg->sync_tolerance ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, recc_front_kernel<3, 1, true, true>, 256, 0)
+                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, recc_front_kernel<3, 1, true, false>, 256, 0);
+            else
+                e = cfg->sync_tolerance ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, recc_bits_kernel<3, true>, 256, 0)
+                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, recc_bits_kernel<3, false>, 256, 0);
             if (e != hipSuccess || nb < 1) nb = 4;
             if (nb > 8) nb = 8;                                  // max_chunks below assumes at most 32 waves per CU
             h->max_waves_bits = (uint32_t)prop.multiProcessorCount * 4u * (uint32_t)nb;
@@ -654,11 +658,14 @@ int run_bits_device(amps_recc *h, uint32_t P)
     fa.tol = h->cfg.sync_tolerance;
     {
         SpanGuard g(h, T_FRONT, P);
-        // exact match: the dedicated bit-domain kernel; tolerant sync: the bit-domain mode of the streaming kernel
-        // (AMPS_RECC_BITS_KERNEL=front selects the latter for the exact match too: the two must agree)
-        if (fa.tol) hipLaunchKernelGGL((recc_front_kernel<3, 1, true, true>), dim3((nwaves + 3) / 4), dim3(256), 0, s, fa);
-        else if (bits_kernel_is_front()) hipLaunchKernelGGL((recc_front_kernel<3, 1, true>), dim3((nwaves + 3) / 4), dim3(256), 0, s, fa);
-        else hipLaunchKernelGGL(recc_bits_kernel<3>, dim3((nwaves + 3) / 4), dim3(256), 0, s, fa);
+        // the dedicated bit-domain kernel; AMPS_RECC_BITS_KERNEL=front selects the bit-domain mode of the streaming kernel
+        // instead (an independent implementation of the same search: the two must agree)
+        const dim3 grid((nwaves + 3) / 4);
+        if (bits_kernel_is_front()) {
+            if (fa.tol) hipLaunchKernelGGL((recc_front_kernel<3, 1, true, true>), grid, dim3(256), 0, s, fa);
+            else hipLaunchKernelGGL((recc_front_kernel<3, 1, true>), grid, dim3(256), 0, s, fa);
+        } else if (fa.tol) hipLaunchKernelGGL((recc_bits_kernel<3, true>), grid, dim3(256), 0, s, fa);
+        else hipLaunchKernelGGL((recc_bits_kernel<3, false>), grid, dim3(256), 0, s, fa);
     }
     HIP_TRY(hipMemsetAsync(h->capq_count, 0, sizeof(uint32_t), s));
     ResolveArgs ra{};

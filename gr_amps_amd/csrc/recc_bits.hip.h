@@ -1,4 +1,5 @@
-// recc_bits.hip.h -- bit-domain trigger correlator behind the fused channelizer (wideband seam, exact match).
+// recc_bits.hip.h -- bit-domain trigger correlator behind the fused channelizer (wideband seam; exact match, or at most
+// cfg.sync_tolerance wrong symbols with TOL = true).
 //
 // chz_fused_kernel leaves only slicer bits in HBM (1 bit per channel sample).  recc_front_kernel<SPS,1,BITS=true> can
 // search them, but it inherits the IQ kernel's layout -- four lanes share one dword of positions, 512 positions per wave
@@ -16,7 +17,7 @@
 
 namespace amps {
 
-template <int SPS>
+template <int SPS, bool TOL = false>
 __global__ __launch_bounds__(256) void recc_bits_kernel(FrontArgs a)
 {
     constexpr int D = AMPS_DEDUP_SYMBOLS * SPS;          // dedup / run window in samples
@@ -128,11 +129,64 @@ __global__ __launch_bounds__(256) void recc_bits_kernel(FrontArgs a)
                     return sym ? acc & x : acc & ~x;
                 };
                 uint32_t acc = ~0u;
+                if constexpr (TOL) {
+                    // tolerant sync (cfg.sync_tolerance): at most a.tol of the 74 symbols differ.  The mismatch words of the
+                    // taps are summed bit-sliced: carry-save adders (Harley-Seal) keep the weights 1, 2, 4 in three words
+                    // and emit one weight-8 word per eight taps, which ripples into the planes 8..64; the 7-bit sums are
+                    // then compared with a.tol plane by plane.  ~2 instructions per tap instead of ~16 for a ripple counter.
+                    auto mism = [&](int i) -> uint32_t {
+                        const int base = 32 * K - SPS * (TRIG - 1 - i);
+                        const uint32_t x = __builtin_amdgcn_alignbit(L[(base >> 5) + 1], L[base >> 5], base & 31);
+                        const bool sym = ((i < 64 ? TRIG_LO >> i : TRIG_HI >> (i - 64)) & 1ull) != 0;
+                        return sym ? ~x : x;
+                    };
+                    auto csa = [](uint32_t &h, uint32_t &l, uint32_t x, uint32_t y, uint32_t z) {
+                        const uint32_t u = x ^ y;
+                        h = (x & y) | (u & z);
+                        l = u ^ z;
+                    };
+                    uint32_t ones = 0u, twos = 0u, fours = 0u, hi[4] = { 0u, 0u, 0u, 0u };   // hi[k]: weight 8 << k
+                    auto add8 = [&](uint32_t e) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) { const uint32_t cy = hi[k] & e; hi[k] ^= e; e = cy; }
+                    };
+                    static_assert(TRIG == 74, "the adder tree below is laid out for 9 x 8 + 2 taps");
+#pragma unroll
+                    for (int blk = 0; blk < 9; blk++) {
+                        const int i0 = 8 * blk;
+                        uint32_t twosA, twosB, foursA, foursB, eights;
+                        csa(twosA, ones, ones, mism(i0), mism(i0 + 1));
+                        csa(twosB, ones, ones, mism(i0 + 2), mism(i0 + 3));
+                        csa(foursA, twos, twos, twosA, twosB);
+                        csa(twosA, ones, ones, mism(i0 + 4), mism(i0 + 5));
+                        csa(twosB, ones, ones, mism(i0 + 6), mism(i0 + 7));
+                        csa(foursB, twos, twos, twosA, twosB);
+                        csa(eights, fours, fours, foursA, foursB);
+                        add8(eights);
+                    }
+                    {
+                        uint32_t t2;
+                        csa(t2, ones, ones, mism(72), mism(73));          // weight-2 carry of the last two taps
+                        const uint32_t c4 = twos & t2; twos ^= t2;
+                        const uint32_t c8 = fours & c4; fours ^= c4;
+                        add8(c8);
+                    }
+                    const uint32_t plane[7] = { ones, twos, fours, hi[0], hi[1], hi[2], hi[3] };
+                    uint32_t gt = 0u, eq = ~0u;
+#pragma unroll
+                    for (int pl = 6; pl >= 0; pl--) {
+                        const uint32_t kb = 0u - ((a.tol >> pl) & 1u);
+                        gt |= eq & plane[pl] & ~kb;
+                        eq &= ~(plane[pl] ^ kb);
+                    }
+                    acc = ~gt;
+                } else {
 #pragma unroll
                 for (int i = TRIG - 16; i < TRIG; i++) acc = tap(i, acc);
                 if (__ballot(acc != 0)) {                                 // rare: the other 58 symbols
 #pragma unroll
                     for (int i = 0; i < TRIG - 16; i++) acc = tap(i, acc);
+                }
                 }
                 const bool hit = __ballot(acc != 0) != 0;
                 // block t-1 can be emitted now that its look-ahead word (lane 0 of this block) exists
