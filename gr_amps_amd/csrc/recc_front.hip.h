@@ -408,14 +408,46 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc
                 // each lane of the quad counts the mismatches of its 18-19 taps in five bit planes (32 positions at
                 // once), the quad adds its four counters, and the 7-bit sums are compared with a.tol plane by plane
                 const int bitbase = slot * TILE + 32 * wq;
-                uint32_t cnt[7] = { 0u, 0u, 0u, 0u, 0u, 0u, 0u };
-                for (int i = part; i < TRIG; i += 4) {
+                // the lane's taps are i = part + 4u, u = 0..18 (the 19th exists for part < 2 only); their mismatch words are
+                // summed with carry-save adders (Harley-Seal, as in recc_bits.hip.h): ~2 instructions per tap for the count
+                // instead of 10 for a five-plane ripple counter
+                auto mism = [&](int u) -> uint32_t {
+                    const int i = part + 4 * u;
                     const int B = (bitbase - SPS * (TRIG - 1 - i)) & (4 * TILE - 1);
                     const int qd = B >> 5;
-                    uint32_t m = ~(__builtin_amdgcn_alignbit(s_g[qd + 1], s_g[qd], B & 31) ^ trig_xor(i));   // 1 = differs
+                    const uint32_t x = ~(__builtin_amdgcn_alignbit(s_g[qd + 1], s_g[qd], B & 31) ^ trig_xor(i));   // 1 = differs
+                    return i < TRIG ? x : 0u;
+                };
+                auto csa = [](uint32_t &h, uint32_t &l, uint32_t x, uint32_t y, uint32_t z) {
+                    const uint32_t w = x ^ y;
+                    h = (x & y) | (w & z);
+                    l = w ^ z;
+                };
+                uint32_t ones = 0u, twos = 0u, fours = 0u, e8 = 0u, e16 = 0u;
+                auto add8 = [&](uint32_t e) { const uint32_t cy = e8 & e; e8 ^= e; e16 ^= cy; };   // at most 19: no carry out of 16
 #pragma unroll
-                    for (int pl = 0; pl < 5; pl++) { const uint32_t cy = cnt[pl] & m; cnt[pl] ^= m; m = cy; }
+                for (int blk = 0; blk < 2; blk++) {
+                    const int u0 = 8 * blk;
+                    uint32_t twosA, twosB, foursA, foursB, eights;
+                    csa(twosA, ones, ones, mism(u0), mism(u0 + 1));
+                    csa(twosB, ones, ones, mism(u0 + 2), mism(u0 + 3));
+                    csa(foursA, twos, twos, twosA, twosB);
+                    csa(twosA, ones, ones, mism(u0 + 4), mism(u0 + 5));
+                    csa(twosB, ones, ones, mism(u0 + 6), mism(u0 + 7));
+                    csa(foursB, twos, twos, twosA, twosB);
+                    csa(eights, fours, fours, foursA, foursB);
+                    add8(eights);
                 }
+                {
+                    uint32_t t2a, c4;
+                    csa(t2a, ones, ones, mism(16), mism(17));
+                    const uint32_t m18 = mism(18);
+                    const uint32_t t2b = ones & m18; ones ^= m18;
+                    csa(c4, twos, twos, t2a, t2b);
+                    const uint32_t c8 = fours & c4; fours ^= c4;
+                    add8(c8);
+                }
+                uint32_t cnt[7] = { ones, twos, fours, e8, e16, 0u, 0u };
 #pragma unroll
                 for (int step = 0; step < 2; step++) {
                     uint32_t cy = 0u;
