@@ -19,7 +19,7 @@ def test_random_streams_match_the_cpu_model(gpu, seed, resident):
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_wideband_random_schedules_give_the_one_shot_records(gpu, seed):
     """Wideband seam: whatever the push schedule (ragged sizes, host or device blocks, sync / split / no drains in between,
-    fused or two-kernel form, exact or tolerant sync on clean bursts) the records equal those of one push."""
+    fused or two-kernel form, exact or tolerant sync) the records equal those of one push with the same tolerance."""
     import numpy as np
     import torch
     from gr_amps_amd import capi, synth_wideband as sw
@@ -55,14 +55,20 @@ def test_wideband_random_schedules_give_the_one_shot_records(gpu, seed):
             got = np.concatenate(recs)
         return got[np.lexsort((got["position"], got["channel"]))]
 
-    ref = run([n], False, 0, False, "sync")
-    assert len(ref) == len(bursts)
-    assert sorted(g["min"].decode() for g in ref) == sorted(v[1] for v in truth.values())
+    # one reference per tolerance: a tolerant trigger can match one sample phase more on one side, which moves the run
+    # centre (the record's position) by a sample -- exact and tolerant runs agree on the words, not on every position
+    ref = {0: run([n], False, 0, False, "sync"), 3: run([n], False, 3, False, "sync")}
+    assert len(ref[0]) == len(ref[3]) == len(bursts)
+    assert sorted(g["min"].decode() for g in ref[0]) == sorted(v[1] for v in truth.values())
+    for a, b in zip(ref[0], ref[3]):
+        assert a["channel"] == b["channel"] and abs(int(a["position"]) - int(b["position"])) <= 1
+        assert np.array_equal(a["word_raw"], b["word_raw"]) and np.array_equal(a["word_dec"], b["word_dec"])
     for _ in range(5):
         cuts = np.sort(rng.integers(1, n, size=int(rng.integers(1, 6))))
         schedule = [int(b - a) for a, b in zip(np.r_[0, cuts], np.r_[cuts, n]) if b > a]
-        got = run(schedule, bool(rng.integers(0, 2)), int(rng.choice([0, 3])), bool(rng.integers(0, 2)), str(rng.choice(["sync", "split", "none"])))
-        assert got.tobytes() == ref.tobytes(), schedule
+        tol = int(rng.choice([0, 3]))
+        got = run(schedule, bool(rng.integers(0, 2)), tol, bool(rng.integers(0, 2)), str(rng.choice(["sync", "split", "none"])))
+        assert got.tobytes() == ref[tol].tobytes(), schedule
 
 
 @pytest.mark.parametrize("seed", [1, 2])

@@ -61,8 +61,11 @@ def test_tolerance_zero_and_nonzero_agree_on_clean_signals(gpu):
             r.push_iq(iq)
             outs.append(r.drain())
     assert len(outs[0]) == 2 * C
-    for o in outs[1:]:
-        assert o.tobytes() == outs[0].tobytes()    # same run centre: the matching phases widen symmetrically... or not at all
+    for o in outs[1:]:       # same bursts and words; a tolerant trigger may match one phase more on one side (centre +-1 sample)
+        assert len(o) == len(outs[0])
+        for a, b in zip(o, outs[0]):
+            assert a["channel"] == b["channel"] and abs(int(a["position"]) - int(b["position"])) <= 1
+            assert np.array_equal(a["word_raw"], b["word_raw"]) and np.array_equal(a["word_dec"], b["word_dec"]) and a["min"] == b["min"]
 
 
 def test_tolerant_sync_on_the_wideband_seam(gpu):
