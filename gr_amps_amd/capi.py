@@ -18,6 +18,8 @@ MEM_HOST, MEM_DEVICE = 0, 1
 FLAG_TIME_KERNELS = 1
 FLAG_MAJORITY = 2
 FLAG_UNFUSED_WIDEBAND = 4
+FLAG_SLICER_PRODUCT = 8
+FLAG_SLICER_SINE = 16
 
 MSG_CLASSES = ("invalid_word_a", "e_zero", "page_response", "registration", "origination", "bad_nawc", "unknown")
 
@@ -160,7 +162,7 @@ class Recc:
     """One handle = `n_channels` independent RECC receivers on one MI355X."""
 
     def __init__(self, n_channels=1, sps=10, max_samples=0, max_bursts=1024, device=-1, time_kernels=False,
-                 stream=None, wideband=None, majority=False, unfused_wideband=False, sync_tolerance=0):
+                 stream=None, wideband=None, majority=False, unfused_wideband=False, sync_tolerance=0, slicer="atan"):
         L = load()
         cfg = Cfg()
         cfg.struct_size = C.sizeof(Cfg)
@@ -170,7 +172,9 @@ class Recc:
         cfg.max_bursts = max_bursts
         cfg.device = device
         cfg.flags = ((FLAG_TIME_KERNELS if time_kernels else 0) | (FLAG_MAJORITY if majority else 0)
-                     | (FLAG_UNFUSED_WIDEBAND if unfused_wideband else 0))
+                     | (FLAG_UNFUSED_WIDEBAND if unfused_wideband else 0)
+                     | (FLAG_SLICER_PRODUCT if slicer in ("product", 1) else 0)
+                     | (FLAG_SLICER_SINE if slicer in ("sine", 2) else 0))
         cfg.stream = stream
         cfg.sync_tolerance = sync_tolerance
         if wideband:

@@ -53,6 +53,8 @@ struct amps_recc {
     float2 *carry[2] = { nullptr, nullptr };
     int carry_cur = 0;
     uint64_t n_done = 0;
+    uint64_t origin = 0;              // absolute index of the stream's first sample (amps_recc_set_origin)
+    int slicer = AMPS_SLICER_ATAN_BOXCAR;   // numeric spec of the slicer (AMPS_RECC_FLAG_SLICER_PRODUCT selects spec B)
     uint32_t r_prev = 0;
     bool origin_locked = false;       // a push has happened since the last reset
     uint64_t *gring = nullptr;
@@ -213,6 +215,7 @@ int reset_state(amps_recc *h)
     HIP_TRY(hipMemsetAsync(h->nbursts_dev, 0, sizeof(uint32_t), s));
     h->carry_cur = 0;
     h->n_done = 0;
+    h->origin = 0;
     h->origin_locked = false;
     h->r_prev = 0;
     int rc = channelizer_reset(h->chz, s);
@@ -260,8 +263,18 @@ int front_blocks_per_cu_for(uint32_t sps)
     default: return 2;
     }
 }
-template <int SPS> void launch_front(const FrontArgs &fa, dim3 grid, hipStream_t s)
+template <int SPS> void launch_front(const FrontArgs &fa, dim3 grid, hipStream_t s, int slicer)
 {
+    if (slicer == AMPS_SLICER_PRODUCT) {
+        if (fa.tol) hipLaunchKernelGGL((recc_front_kernel<SPS, 1, false, true, AMPS_SLICER_PRODUCT>), grid, dim3(256), 0, s, fa);
+        else hipLaunchKernelGGL((recc_front_kernel<SPS, 1, false, false, AMPS_SLICER_PRODUCT>), grid, dim3(256), 0, s, fa);
+        return;
+    }
+    if (slicer == AMPS_SLICER_SINE) {
+        if (fa.tol) hipLaunchKernelGGL((recc_front_kernel<SPS, 1, false, true, AMPS_SLICER_SINE>), grid, dim3(256), 0, s, fa);
+        else hipLaunchKernelGGL((recc_front_kernel<SPS, 1, false, false, AMPS_SLICER_SINE>), grid, dim3(256), 0, s, fa);
+        return;
+    }
     if (fa.tol) { hipLaunchKernelGGL((recc_front_kernel<SPS, 1, false, true>), grid, dim3(256), 0, s, fa); return; }
     switch (front_depth()) {
     case 3: hipLaunchKernelGGL((recc_front_kernel<SPS, 3>), grid, dim3(256), 0, s, fa); break;
@@ -275,16 +288,16 @@ bool sps_supported(uint32_t sps)
     switch (sps) { case 3: case 4: case 5: case 6: case 8: case 10: case 12: return true; default: return false; }
 }
 
-int dispatch_front(uint32_t sps, const FrontArgs &fa, dim3 grid, hipStream_t s)
+int dispatch_front(uint32_t sps, const FrontArgs &fa, dim3 grid, hipStream_t s, int slicer)
 {
     switch (sps) {
-    case 3: launch_front<3>(fa, grid, s); break;
-    case 4: launch_front<4>(fa, grid, s); break;
-    case 5: launch_front<5>(fa, grid, s); break;
-    case 6: launch_front<6>(fa, grid, s); break;
-    case 8: launch_front<8>(fa, grid, s); break;
-    case 10: launch_front<10>(fa, grid, s); break;
-    case 12: launch_front<12>(fa, grid, s); break;
+    case 3: launch_front<3>(fa, grid, s, slicer); break;
+    case 4: launch_front<4>(fa, grid, s, slicer); break;
+    case 5: launch_front<5>(fa, grid, s, slicer); break;
+    case 6: launch_front<6>(fa, grid, s, slicer); break;
+    case 8: launch_front<8>(fa, grid, s, slicer); break;
+    case 10: launch_front<10>(fa, grid, s, slicer); break;
+    case 12: launch_front<12>(fa, grid, s, slicer); break;
     default: return -EINVAL;
     }
     return 0;
@@ -321,12 +334,13 @@ int run_iq_device(amps_recc *h, const float2 *iq, uint64_t ld, uint32_t nsamp)
         fa.n_done = h->n_done; fa.gring = h->gring; fa.ring_mask = h->ring_words - 1; fa.ring_words = h->ring_words;
         fa.det = h->det; fa.detcount = h->detcount; fa.max_chunks = h->max_chunks; fa.det_cap = h->det_cap;
         fa.tol = h->cfg.sync_tolerance;
+        fa.force_ones = (h->slicer == AMPS_SLICER_PRODUCT && h->n_done == h->origin) ? h->sps : 0u;   // spec B: no partner yet
         fa.status = h->status; fa.dbg_d = h->dbg_d; fa.dbg_S = h->dbg_S; fa.dbg_channel = 0;
         SpanGuard g(h, T_FRONT, P);
         if (debug_sync_enabled())
             std::fprintf(stderr, "amps_recc[debug]: front waves=%u span=%u Tc=%u C=%u P=%u avail=%u r_prev=%u ld=%llu n_done=%llu ring_words=%u max_chunks=%u det_cap=%u\n",
                          nwaves, span, Tc, h->C, P, avail, h->r_prev, (unsigned long long)ld, (unsigned long long)h->n_done, h->ring_words, h->max_chunks, h->det_cap);
-        int rc = dispatch_front(h->sps, fa, dim3((nwaves + 3) / 4), s);
+        int rc = dispatch_front(h->sps, fa, dim3((nwaves + 3) / 4), s, h->slicer);
         if (rc) return rc;
     }
     if (int rc = debug_sync(h, "front")) return rc;
@@ -399,7 +413,11 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
     if (cfg->struct_size != sizeof(amps_recc_cfg_t)) return -EINVAL;
     if (cfg->n_channels < 1 || cfg->max_bursts < 1) return -EINVAL;
     if (cfg->max_samples_per_push && !sps_supported(cfg->samples_per_symbol)) return -EINVAL;
+    // the channelizer's geometry (M = 1024, D = 512 at 30.72 Msps) delivers 60 ksps = 3 samples per Manchester symbol, and the
+    // bit-domain kernels behind it are built for exactly that
+    if (cfg->wideband_channels && (cfg->samples_per_symbol != 3 || cfg->max_samples_per_push == 0)) return -EINVAL;
     if (cfg->sync_tolerance > AMPS_RECC_MAX_SYNC_TOLERANCE) return -EINVAL;
+    if ((cfg->flags & AMPS_RECC_FLAG_SLICER_PRODUCT) && (cfg->flags & AMPS_RECC_FLAG_SLICER_SINE)) return -EINVAL;
     if (cfg->n_channels >= (1u << (64 - CAPQ_POS_BITS))) return -EINVAL;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return -ENODEV;
@@ -414,6 +432,8 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
     h->device = dev;
     h->C = cfg->n_channels;
     h->sps = cfg->samples_per_symbol;
+    h->slicer = (cfg->flags & AMPS_RECC_FLAG_SLICER_PRODUCT) ? AMPS_SLICER_PRODUCT
+              : (cfg->flags & AMPS_RECC_FLAG_SLICER_SINE) ? AMPS_SLICER_SINE : AMPS_SLICER_ATAN_BOXCAR;
     h->timing = (cfg->flags & AMPS_RECC_FLAG_TIME_KERNELS) != 0;
     h->timing_mode = h->timing ? AMPS_RECC_TIMING_ALL : AMPS_RECC_TIMING_OFF;
     if (cfg->stream) h->stream = (hipStream_t)cfg->stream;
@@ -709,7 +729,7 @@ int amps_recc_push_wideband(amps_recc_t *h, const float *iq, size_t nsamp, int m
     int rc;
     {
         SpanGuard g(h, T_CHANNELIZER, nsamp);
-        rc = channelizer_run(h->chz, (const float2 *)iq, nsamp, mem, h->stream, &chan_iq, &ld, &nout, fused, h->gring, h->ring_words, h->n_done);
+        rc = channelizer_run(h->chz, (const float2 *)iq, nsamp, mem, h->stream, &chan_iq, &ld, &nout, fused, h->gring, h->ring_words, h->n_done, h->slicer);
     }
     if (rc) return rc;
     if (nout > h->cfg.max_samples_per_push) return -E2BIG;
@@ -904,6 +924,7 @@ int amps_recc_set_origin(amps_recc_t *h, uint64_t first_sample)
     if (!h->carry[0]) return -ENOSYS;
     if (h->n_done != 0 || h->r_prev != 0 || h->origin_locked) return -EBUSY;     // only on a fresh or reset handle
     h->n_done = first_sample;
+    h->origin = first_sample;
     return 0;
 }
 

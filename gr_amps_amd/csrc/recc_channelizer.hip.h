@@ -36,6 +36,7 @@
 #include <type_traits>
 #include <vector>
 #include "amps_recc.h"
+#include "amps_recc_numerics.h"
 
 namespace amps {
 
@@ -84,19 +85,61 @@ struct ChzArgs {
     uint64_t *gring;         // [C][ring_words]
     uint32_t ring_words;
     uint64_t n_done;         // absolute channel-stream sample index of frame 0 (multiple of 64)
+    uint32_t stream_start;   // frame 0 of this launch is the first frame of the stream (spec B: its first 3 bits are ones)
 };
 constexpr int CHZ_PRE = 4;   // frames re-run in front of a workgroup's range to rebuild per-bin demod state (even)
 
 typedef float cf2 __attribute__((ext_vector_type(2)));
 
-// (a.x b.x - a.y b.y, a.y b.x + a.x b.y) as one v_pk_mul + one v_pk_fma (swap / negate ride on op_sel / neg modifiers);
-// the plain expression compiles to 4 mul + add + sub with contraction off -- 48 more issue slots per frame
+// Packed fp32 with operand modifiers.  hipcc materialises every swap / negate / broadcast of a packed operand with v_mov /
+// v_xor and keeps broadcast constants as duplicated register PAIRS (the 32 fold coefficients cost 64 VGPRs, the six pass
+// twiddles 24); the VOP3P modifiers do all of that for free, so the few shapes the pipeline needs are written as single
+// instructions.  (The compiler treats an inline-asm producer conservatively for the gfx950 forwarding hazard and inserts
+// the wait state itself.)  Every form computes exactly the IEEE operations of the plain expression next to it.
+//
+// (a.x b.x - a.y b.y, a.y b.x + a.x b.y):  m = (a.y * -b.y, a.x * b.y);  r = a * (b.x, b.x) + m
 __device__ __forceinline__ cf2 cmul(cf2 a, cf2 b)
 {
-    const cf2 m = (cf2){ a.y, a.x } * (cf2){ -b.y, b.y };
-    return __builtin_elementwise_fma(a, (cf2){ b.x, b.x }, m);
+    cf2 m, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[0,1]" : "=v"(m) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(m));
+    return r;
+}
+// the same with a wave-uniform twiddle held in an SGPR pair (the W16 constants of the radix-16 pass)
+__device__ __forceinline__ cf2 cmul_s(cf2 a, cf2 b)
+{
+    cf2 m, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[0,1]" : "=v"(m) : "v"(a), "s"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "s"(b), "v"(m));
+    return r;
 }
 __device__ __forceinline__ cf2 mul_mi(cf2 a) { return (cf2){ a.y, -a.x }; }   // a * (-i)
+// v + (-i) d = (v.x + d.y, v.y - d.x)   and   v - (-i) d = (v.x - d.y, v.y + d.x)
+__device__ __forceinline__ cf2 add_mi(cf2 v, cf2 d)
+{
+    cf2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(v), "v"(d));
+    return r;
+}
+__device__ __forceinline__ cf2 sub_mi(cf2 v, cf2 d)
+{
+    cf2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(v), "v"(d));
+    return r;
+}
+// a * (c.x, c.x) + s  and  a * (c.y, c.y) + s : one coefficient PAIR serves two taps
+__device__ __forceinline__ cf2 fma_lo(cf2 a, cf2 c, cf2 s)
+{
+    cf2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(c), "v"(s));
+    return r;
+}
+__device__ __forceinline__ cf2 fma_hi(cf2 a, cf2 c, cf2 s)
+{
+    cf2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(a), "v"(c), "v"(s));
+    return r;
+}
 
 // History on MI355X (1 GiB of wideband per launch, fused kernel ms): LDS sample ring 1.49 -> register delay lines 1.26 ->
 // fused discriminator 1.02 -> packed complex multiply 0.90 -> lock-step 4-way discriminator 0.87 -> two-frame prefetch 0.83
@@ -123,8 +166,8 @@ __host__ __device__ constexpr int cpad(int n) { return n + (n >> 4); }
 
 __device__ __forceinline__ void dft4(cf2 a0, cf2 a1, cf2 a2, cf2 a3, cf2 (&o)[4])
 {
-    const cf2 v0 = a0 + a2, v1 = a0 - a2, v2 = a1 + a3, v3 = mul_mi(a1 - a3);
-    o[0] = v0 + v2; o[1] = v1 + v3; o[2] = v0 - v2; o[3] = v1 - v3;
+    const cf2 v0 = a0 + a2, v1 = a0 - a2, v2 = a1 + a3, d = a1 - a3;
+    o[0] = v0 + v2; o[1] = add_mi(v1, d); o[2] = v0 - v2; o[3] = sub_mi(v1, d);
 }
 
 // e^{-2 pi i num / den}, argument reduced exactly (sincospif)
@@ -140,7 +183,7 @@ __device__ __forceinline__ cf2 chz_twiddle(int num, int den)
 // branches 0,1; SB for 2,3) counts the samples of this batch already shifted in.  PAR = parity of the absolute frame index
 // m: which coefficient set a branch uses alternates with it.  All register indices are compile-time constants.
 template <int P, int PAR, int SA, int SB>
-__device__ __forceinline__ void chz_fold_p1(const cf2 (&ext)[4][P + 2], const float (&coef)[4][P], cf2 *A, int t)
+__device__ __forceinline__ void chz_fold_p1(const cf2 (&ext)[4][P + 2], const cf2 (&coef)[4][P / 2], cf2 *A, int t)
 {
     constexpr int SW = 2 * ((PAR + 1) & 1);
     cf2 x[4];
@@ -149,7 +192,10 @@ __device__ __forceinline__ void chz_fold_p1(const cf2 (&ext)[4][P + 2], const fl
         const int sh = jb < 2 ? SA : SB;
         cf2 s = { 0.f, 0.f };
 #pragma unroll
-        for (int q = 0; q < P; q++) s = __builtin_elementwise_fma(ext[jb][sh + q], (cf2){ coef[jb ^ SW][q], coef[jb ^ SW][q] }, s);
+        for (int q = 0; q < P; q += 2) {                            // taps q, q+1 share one coefficient pair
+            s = fma_lo(ext[jb][sh + q], coef[jb ^ SW][q / 2], s);
+            s = fma_hi(ext[jb][sh + q + 1], coef[jb ^ SW][q / 2], s);
+        }
         x[jb] = s;
     }
     cf2 o[4];
@@ -163,7 +209,7 @@ __device__ __forceinline__ void chz_fold_p1(const cf2 (&ext)[4][P + 2], const fl
 // the delay lines are shifted once per batch, by two samples per branch (shifting per frame cost 150 v_mov per batch,
 // a tenth of the instruction stream).
 template <int P>
-__device__ __forceinline__ void chz_fold_batch(cf2 (&line)[4][P], const float (&coef)[4][P], const cf2 (&nx)[CHZ_BATCH][2], cf2 *bufA, int t)
+__device__ __forceinline__ void chz_fold_batch(cf2 (&line)[4][P], const cf2 (&coef)[4][P / 2], const cf2 (&nx)[CHZ_BATCH][2], cf2 *bufA, int t)
 {
     cf2 ext[4][P + 2];
 #pragma unroll
@@ -206,15 +252,15 @@ __device__ __forceinline__ void chz_p2(cf2 *A, const cf2 *tab, int lane)
 #pragma unroll
     for (int b = 0; b < 4; b++) dft4(u[b], u[4 + b], u[8 + b], u[12 + b], v[b]);
     constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
-    v[1][1] = cmul(v[1][1], (cf2){ C1, -S1 });                  // W16^1
-    v[1][2] = cmul(v[1][2], (cf2){ R2, -R2 });                  // W16^2
-    v[1][3] = cmul(v[1][3], (cf2){ S1, -C1 });                  // W16^3
-    v[2][1] = cmul(v[2][1], (cf2){ R2, -R2 });                  // W16^2
+    v[1][1] = cmul_s(v[1][1], (cf2){ C1, -S1 });                // W16^1
+    v[1][2] = cmul_s(v[1][2], (cf2){ R2, -R2 });                // W16^2
+    v[1][3] = cmul_s(v[1][3], (cf2){ S1, -C1 });                // W16^3
+    v[2][1] = cmul_s(v[2][1], (cf2){ R2, -R2 });                // W16^2
     v[2][2] = mul_mi(v[2][2]);                                  // W16^4 = -i
-    v[2][3] = cmul(v[2][3], (cf2){ -R2, -R2 });                 // W16^6
-    v[3][1] = cmul(v[3][1], (cf2){ S1, -C1 });                  // W16^3
-    v[3][2] = cmul(v[3][2], (cf2){ -R2, -R2 });                 // W16^6
-    v[3][3] = cmul(v[3][3], (cf2){ -C1, S1 });                  // W16^9
+    v[2][3] = cmul_s(v[2][3], (cf2){ -R2, -R2 });               // W16^6
+    v[3][1] = cmul_s(v[3][1], (cf2){ S1, -C1 });                // W16^3
+    v[3][2] = cmul_s(v[3][2], (cf2){ -R2, -R2 });               // W16^6
+    v[3][3] = cmul_s(v[3][3], (cf2){ -C1, S1 });                // W16^9
     // all reads of this wave precede its writes in program order; nobody else touches this frame during pass 2
     cf2 *dst = A + 17 * (lane - k) + k;                         // cpad(16 (i-k) + k + 4 r) = 17 (i-k) + k + 4 r + (r >> 2)
 #pragma unroll
@@ -246,7 +292,7 @@ __device__ __forceinline__ void chz_p4(const cf2 *Cb, const cf2 (&tw)[3], int t,
 
 // per-thread constants of the pipeline
 template <int P> struct ChzRegs {
-    float coef[4][P];        // h[t + 256 j + qM]
+    cf2 coef[4][P / 2];      // (h[t + 256 j + qM], h[t + 256 j + (q+1)M]), q even
     cf2 tw3[3], tw4[3];      // pass 3 / pass 4 twiddles
 };
 template <int P>
@@ -255,7 +301,7 @@ __device__ __forceinline__ void chz_setup(ChzRegs<P> &R, const float *taps, cf2 
 #pragma unroll
     for (int j = 0; j < 4; j++)
 #pragma unroll
-        for (int q = 0; q < P; q++) R.coef[j][q] = taps[t + 256 * j + q * CHZ_M];
+        for (int q = 0; q < P; q += 2) R.coef[j][q / 2] = (cf2){ taps[t + 256 * j + q * CHZ_M], taps[t + 256 * j + (q + 1) * CHZ_M] };
 #pragma unroll
     for (int r = 1; r < 4; r++) { R.tw3[r - 1] = chz_twiddle(r * (t & 63), 256); R.tw4[r - 1] = chz_twiddle(r * t, 1024); }
     if (t < 64) tab[t] = chz_twiddle((t >> 2) * (t & 3), 64);   // tab[4 r + k]
@@ -395,9 +441,41 @@ __device__ __forceinline__ void chz_bins(const cf2 (&y)[4], cf2 (&prev)[4], f2 (
     for (int j = 0; j < 4; j++) prev[j] = y[j];
 }
 
+// Slicer spec B (include/amps_recc_numerics.h): g = !signbit(yi * pr - yr * pi) with p = the same bin three frames (one
+// Manchester symbol) earlier.  One v_pk_mul (the partner's halves swapped by op_sel), one v_sub and one v_alignbit per bin:
+// the register collects SIGN bits, newest at bit 0, and is bit-reversed and inverted when it is stored.
+__device__ __forceinline__ void chz_slice_prod(const cf2 (&y)[4], const cf2 (&p)[4], uint32_t (&gw)[4])
+{
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        cf2 m;                                                    // (yr * pi, yi * pr) = (b, a): the partner's halves swapped by op_sel
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(m) : "v"(y[j]), "v"(p[j]));
+        const float sdiff = m.y - m.x;
+        gw[j] = __builtin_amdgcn_alignbit(gw[j], __float_as_uint(sdiff), 31);   // (gw << 1) | signbit
+    }
+}
+
+// Slicer spec C: d' = Im(y conj(prev)) = fmaf(yi, pr, -(yr * pi)) (the `im` of spec A's conj-product, no arctangent), spec A's
+// 3-sample boxcar in its aligned-pair order, g = !signbit(S').  Sign bits are collected like spec B's.
+template <int PAR>
+__device__ __forceinline__ void chz_bins_sine(const cf2 (&y)[4], cf2 (&prev)[4], f2 (&d1)[2], f2 (&d2)[2], uint32_t (&gw)[4])
+{
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const cf2 y0 = y[2 * h], p0 = prev[2 * h], y1 = y[2 * h + 1], p1 = prev[2 * h + 1];
+        const f2 d = { __builtin_fmaf(y0.y, p0.x, -(y0.x * p0.y)), __builtin_fmaf(y1.y, p1.x, -(y1.x * p1.y)) };
+        const f2 s = PAR == 0 ? (d2[h] + d1[h]) + d : d2[h] + (d1[h] + d);
+        gw[2 * h] = __builtin_amdgcn_alignbit(gw[2 * h], __float_as_uint(s.x), 31);
+        gw[2 * h + 1] = __builtin_amdgcn_alignbit(gw[2 * h + 1], __float_as_uint(s.y), 31);
+        d2[h] = d1[h]; d1[h] = d;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) prev[j] = y[j];
+}
+
 // P = 8 is held to 256 VGPRs = two waves per SIMD (left alone the allocator takes 258 and halves the occupancy;
 // __launch_bounds__(256, 3) would force 168 and spill: 2.9 ms instead of 1.0).  P = 16 needs ~390: one wave per SIMD.
-template <int P>
+template <int P, int SL = AMPS_SLICER_ATAN_BOXCAR>
 __global__ __launch_bounds__(256, P <= 8 ? 2 : 1) void chz_fused_kernel(ChzArgs a)
 {
     constexpr int M = CHZ_M, D = CHZ_D;
@@ -425,7 +503,10 @@ __global__ __launch_bounds__(256, P <= 8 ? 2 : 1) void chz_fused_kernel(ChzArgs 
     }
     cf2 prev[4] = {};
     f2 d1[2] = {}, d2[2] = {};                                    // the last two demod floats of bins (0,1) and (2,3)
-    uint32_t gw[4] = { ~0u, ~0u, ~0u, ~0u };
+    cf2 hist[3][4] = {};                                          // spec B: this lane's bins in frames 1..3 of the previous batch
+    uint32_t gw[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) gw[j] = SL != AMPS_SLICER_ATAN_BOXCAR ? 0u : ~0u;   // "ones before the stream" in either representation
     const uint64_t mask32 = 2ull * a.ring_words - 1;
 
     // the inputs of a whole batch are loaded one batch (~7 us) ahead
@@ -448,18 +529,45 @@ __global__ __launch_bounds__(256, P <= 8 ? 2 : 1) void chz_fused_kernel(ChzArgs 
 #pragma unroll
         for (int g = 0; g < CHZ_BATCH; g++) chz_p3(bufA + g * CHZ_FB, bufC + g * CHZ_FB, R.tw3, t);
         __syncthreads();
+        if constexpr (SL == AMPS_SLICER_PRODUCT) {
+            // frame g pairs with frame g - 3: frames 0..2 with frames 1..3 of the previous batch, frame 3 with frame 0
+            cf2 y0[4];
+            chz_p4(bufC, R.tw4, t, y0);
+            chz_slice_prod(y0, hist[0], gw);
+            chz_p4(bufC + CHZ_FB, R.tw4, t, hist[0]);             // frame 1 takes the place of the value it replaces
+            chz_slice_prod(hist[0], hist[1], gw);
+            chz_p4(bufC + 2 * CHZ_FB, R.tw4, t, hist[1]);
+            chz_slice_prod(hist[1], hist[2], gw);
+            chz_p4(bufC + 3 * CHZ_FB, R.tw4, t, hist[2]);
+            chz_slice_prod(hist[2], y0, gw);
+        } else if constexpr (SL == AMPS_SLICER_SINE) {
+            const bool pre = a.stream_start && f < 0;             // frames before the stream are exactly +0 (the FFT of zeros may hold -0)
+#pragma unroll
+            for (int g = 0; g < CHZ_BATCH; g++) {
+                cf2 y[4];
+                chz_p4(bufC + g * CHZ_FB, R.tw4, t, y);
+                if (pre) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) y[j] = (cf2){ 0.f, 0.f };
+                }
+                if (g & 1) chz_bins_sine<1>(y, prev, d1, d2, gw); else chz_bins_sine<0>(y, prev, d1, d2, gw);
+            }
+        } else {
 #pragma unroll
         for (int g = 0; g < CHZ_BATCH; g++) {
             cf2 y[4];
             chz_p4(bufC + g * CHZ_FB, R.tw4, t, y);
             if (g & 1) chz_bins<1>(y, prev, d1, d2, gw); else chz_bins<0>(y, prev, d1, d2, gw);
         }
+        }
         if (f >= f0 && ((f + 3) & 31) == 31) {                    // 32 real frames collected (f0 is a multiple of 64)
             const uint64_t n = a.n_done + (uint64_t)(f + 3);      // absolute index of the newest bit
 #pragma unroll
             for (int j = 0; j < 4; j++) {                         // channel / ring address recomputed here: 12 fewer live VGPRs
                 const uint32_t ch = ((uint32_t)(t + 256 * j) - a.first_bin) & (M - 1);
-                if (ch < a.n_channels) ((uint32_t *)(a.gring + (uint64_t)ch * a.ring_words))[(n >> 5) & mask32] = gw[j];
+                uint32_t word = SL != AMPS_SLICER_ATAN_BOXCAR ? ~__builtin_bitreverse32(gw[j]) : gw[j];
+                if (SL == AMPS_SLICER_PRODUCT && a.stream_start && f + 3 == 31) word |= 7u;   // no partner yet: g = 1
+                if (ch < a.n_channels) ((uint32_t *)(a.gring + (uint64_t)ch * a.ring_words))[(n >> 5) & mask32] = word;
             }
         }
     }
@@ -586,7 +694,8 @@ inline int channelizer_create(ChannelizerState &z, const amps_recc_cfg_t &cfg, h
 //                 at absolute sample index n_done.. ; consumes a multiple of 64 frames.
 inline int channelizer_run(ChannelizerState &z, const float2 *iq, size_t nsamp, int mem, hipStream_t s,
                            const float2 **chan_iq, uint64_t *ld, uint32_t *nframes_out,
-                           bool fused = false, uint64_t *gring = nullptr, uint32_t ring_words = 0, uint64_t n_done = 0)
+                           bool fused = false, uint64_t *gring = nullptr, uint32_t ring_words = 0, uint64_t n_done = 0,
+                           int slicer = AMPS_SLICER_ATAN_BOXCAR)
 {
     if (!z.enabled) return -ENOSYS;
     const float2 *d = iq;
@@ -621,8 +730,15 @@ inline int channelizer_run(ChannelizerState &z, const float2 *iq, size_t nsamp, 
         a.frames_per_wg = fpw; a.first_bin = z.first_bin; a.n_channels = z.C;
         a.odd_start = 0;
         a.gring = gring; a.ring_words = ring_words; a.n_done = n_done;
+        a.stream_start = z.frames_done == 0 ? 1u : 0u;
         const uint32_t nwg = (nframes + fpw - 1) / fpw;
-        if (fused) {
+        if (fused && slicer == AMPS_SLICER_PRODUCT) {
+            if (z.P == 8) hipLaunchKernelGGL((chz_fused_kernel<8, AMPS_SLICER_PRODUCT>), dim3(nwg), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((chz_fused_kernel<16, AMPS_SLICER_PRODUCT>), dim3(nwg), dim3(256), 0, s, a);
+        } else if (fused && slicer == AMPS_SLICER_SINE) {
+            if (z.P == 8) hipLaunchKernelGGL((chz_fused_kernel<8, AMPS_SLICER_SINE>), dim3(nwg), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((chz_fused_kernel<16, AMPS_SLICER_SINE>), dim3(nwg), dim3(256), 0, s, a);
+        } else if (fused) {
             if (z.P == 8) hipLaunchKernelGGL(chz_fused_kernel<8>, dim3(nwg), dim3(256), 0, s, a);
             else hipLaunchKernelGGL(chz_fused_kernel<16>, dim3(nwg), dim3(256), 0, s, a);
         } else {

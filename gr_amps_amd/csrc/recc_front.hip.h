@@ -88,6 +88,7 @@ struct FrontArgs {
     float    *dbg_S;
     uint32_t dbg_channel;
     uint32_t tol;            // TOL kernels: accepted mismatching trigger symbols (cfg.sync_tolerance)
+    uint32_t force_ones;     // spec B: rel samples [0, force_ones) have no partner yet (stream start): g = 1
 };
 
 typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));  // two fc32 samples, 8-byte aligned
@@ -178,6 +179,11 @@ __device__ __forceinline__ f2 conj_product(f2 x, f2 p)
     return __builtin_elementwise_fma(x, (f2){ p.x, p.x }, m);
 }
 
+// spec C: only the imaginary part of the two conj-products, fmaf(xi, pr, -(xr*pi)) -- the `im` of spec A
+__device__ __forceinline__ f2 sine_pair(float4 s, float pr, float pi_)
+{
+    return (f2){ __builtin_fmaf(s.y, pr, -(s.x * pi_)), __builtin_fmaf(s.w, s.x, -(s.z * s.y)) };
+}
 __device__ __forceinline__ f2 fm_phase_pair(float4 s, float pr, float pi_)
 {
     const f2 xa = { s.x, s.y }, xb = { s.z, s.w };
@@ -205,6 +211,11 @@ constexpr int DHIST = 16;
 __host__ __device__ constexpr int didx(int n) { return n + (n >> 3); }   // n = DHIST + tile-local sample
 constexpr int DBUF = ((didx(DHIST + TILE - 1) + 1 + 7) / 8) * 8;        // 600 floats per buffer
 constexpr int GW32 = 4 * TILE / 32;                                     // 64 dwords: 4-tile bit ring (+1 mirror)
+// Spec B stages the tile's raw samples instead: 16 samples of history then the 512 of the tile, as float2, every 8
+// padded by one (lane stride 18 banks: the 8-byte reads of a 32-lane group cover all 64 banks once)
+constexpr int XHIST = 16;
+__host__ __device__ constexpr int xidx(int n) { return n + (n >> 3); }   // n = XHIST + tile-local sample
+constexpr int XBUF = ((xidx(XHIST + TILE - 1) + 1 + 7) / 8) * 8;        // 600 float2 per wave
 
 // trigger symbol i as an xor mask for the xnor test (symbol 1 -> 0, symbol 0 -> ~0)
 __device__ __forceinline__ uint32_t trig_xor(int i)
@@ -230,14 +241,19 @@ __device__ __forceinline__ float lane63(float v)
 // TOL = true replaces the exact trigger match by "at most a.tol of the 74 symbols differ" (a
 // divergence from the reference's memmem, off by default): no prefilter is sound then, so every tile pays a
 // bit-sliced population count over all 74 taps (~350 instructions per lane per tile instead of ~25).
-template <int SPS, int DEPTH, bool BITS = false, bool TOL = false>
+// SL = AMPS_SLICER_PRODUCT: slicer spec B (sign of Im(x[n] conj(x[n-SPS]))) instead of discriminator + boxcar: the tile's
+// raw samples are staged in the wave's LDS buffer and each lane slices 8 consecutive samples with one v_pk_mul, one
+// v_sub and one v_alignbit each -- the kernel is then bound by its HBM reads alone.
+template <int SPS, int DEPTH, bool BITS = false, bool TOL = false, int SL = AMPS_SLICER_ATAN_BOXCAR>
 __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc_front_kernel(FrontArgs a)
 {
+    constexpr bool PROD = SL == AMPS_SLICER_PRODUCT;
+    static_assert(!PROD || (!BITS && SPS <= XHIST), "spec B runs on IQ");
     static_assert(SPS >= 2 && SPS <= 16, "samples per symbol");
     constexpr int H = SPS - 1;                  // boxcar history
     constexpr int D = AMPS_DEDUP_SYMBOLS * SPS; // dedup / run window in samples (<= 32)
     static_assert(H <= DHIST, "history prefix too small");
-    __shared__ float    s_d_all[4][BITS ? 8 : 2 * DBUF];   // demod buffers: not used in the bit domain (keeps its LDS at 2 KB)
+    __shared__ float    s_d_all[4][BITS ? 8 : PROD ? 2 * XBUF : 2 * DBUF];   // demod buffers (spec B: one float2 sample buffer): not used in the bit domain (keeps its LDS at 2 KB)
     __shared__ uint32_t s_g_all[4][GW32 + 2];   // [GW32] mirrors [0] so a tap can always read dwords qd, qd+1
     __shared__ uint32_t s_m_all[4][GW32];
 
@@ -308,7 +324,7 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc
     s_g[lane] = ~0u;
     if (lane < 2) s_g[GW32 + lane] = ~0u;
     s_m[lane] = 0u;
-    if constexpr (!BITS) for (int i = lane; i < 2 * DBUF; i += 64) s_d[i] = 0.f;
+    if constexpr (!BITS) for (int i = lane; i < (PROD ? 2 * XBUF : 2 * DBUF); i += 64) s_d[i] = 0.f;
 
     float4 cur[4], nxt[DEPTH][4];                // tile k in use, tiles k+1..k+DEPTH in flight (DEPTH x 4 KiB per wave)
     float last_x = 0.f, last_y = 0.f;            // last sample of the previous tile (wave-uniform)
@@ -344,6 +360,49 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc
                 s_g[slot * (TILE / 32) + lane] = w;
                 if (slot == 0 && lane < 2) s_g[GW32 + lane] = w;      // mirror of dwords 0,1
             }
+        } else if constexpr (PROD) {
+        // ---- spec B: stage the tile's samples in LDS, then every lane slices samples 8*lane .. 8*lane+7 ----
+        if (k + DEPTH < K) load_tile(nxt[DEPTH - 1], t0 + DEPTH * TILE);
+        f2 *const xs = (f2 *)s_d;
+        {
+            f2 *const xw = xs + 2 * lane + (lane >> 2);              // xidx(XHIST + 128 q + 2 lane + e) = const + this
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                xw[xidx(XHIST + 128 * q)] = (f2){ cur[q].x, cur[q].y };
+                xw[xidx(XHIST + 128 * q) + 1] = (f2){ cur[q].z, cur[q].w };
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        {
+            const f2 *const xr = xs + 9 * lane;
+            f2 v[SPS + 8];
+#pragma unroll
+            for (int m = 0; m < SPS + 8; m++) v[m] = xr[xidx(XHIST - SPS + m)];
+            const bool dbg = a.dbg_d && (uint32_t)c == a.dbg_channel && k >= 0;
+            uint32_t acc = 0u;                                       // sign bits, newest at bit 0
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const f2 m = v[SPS + q] * (f2){ v[q].y, v[q].x };    // (xr * pi, xi * pr) = (b, a)
+                const float sd = m.y - m.x;
+                acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(sd), 31);
+                if (dbg) {
+                    int64_t rel = t0 + 8 * lane + q;
+                    if (rel < (int64_t)a.P) { a.dbg_d[rel] = 0.f; a.dbg_S[rel] = rel < (int64_t)a.force_ones ? 0.f : sd; }
+                }
+            }
+            unsigned byte = (~__builtin_bitreverse32(acc)) >> 24;    // g = !signbit, sample 8*lane+q at bit q
+            if (t0 == 0 && a.force_ones) {                           // wave-uniform: the first tile of a stream
+                const int nf = (int)a.force_ones - 8 * lane;         // samples of this lane that have no partner yet
+                if (nf > 0) byte |= nf >= 8 ? 0xffu : (1u << nf) - 1u;
+            }
+            __builtin_amdgcn_wave_barrier();                         // everybody has read the history prefix
+            if (lane >= 56) {                                        // samples 496..511 become the next tile's history
+                xs[xidx(2 * (lane - 56))] = (f2){ cur[3].x, cur[3].y };
+                xs[xidx(2 * (lane - 56)) + 1] = (f2){ cur[3].z, cur[3].w };
+            }
+            ((uint8_t *)s_g)[slot * (TILE / 8) + lane] = (uint8_t)byte;
+            if (slot == 0 && lane < 8) ((uint8_t *)s_g)[GW32 * 4 + lane] = (uint8_t)byte;   // mirror of dwords 0,1
+        }
         } else {
         // ---- P1: prefetch the next tile, demodulate this one into LDS ----
         if (k + DEPTH < K) load_tile(nxt[DEPTH - 1], t0 + DEPTH * TILE);
@@ -353,7 +412,7 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc
             const float ex = q == 0 ? last_x : lane63(cur[q - 1].z);
             const float ey = q == 0 ? last_y : lane63(cur[q - 1].w);
             const float pr = shift_in(cur[q].z, ex), pi_ = shift_in(cur[q].w, ey);
-            const f2 dd = fm_phase_pair(cur[q], pr, pi_);
+            const f2 dd = SL == AMPS_SLICER_SINE ? sine_pair(cur[q], pr, pi_) : fm_phase_pair(cur[q], pr, pi_);
             const float d0 = dd.x, d1 = dd.y;
             dw[didx(DHIST + 128 * q)] = d0;
             dw[didx(DHIST + 128 * q) + 1] = d1;
@@ -384,7 +443,8 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc
 #pragma unroll
                 for (int u = lead ? 0 : 1; u < npairs; u++) s = s + (v[j0 + 2 * u] + v[j0 + 2 * u + 1]);
                 if (trail) s = s + v[q + H];
-                byte |= (s >= 0.0f ? 1u : 0u) << q;
+                if constexpr (SL == AMPS_SLICER_SINE) byte |= (~__float_as_uint(s) >> 31) << q;   // g = !signbit(S')
+                else byte |= (s >= 0.0f ? 1u : 0u) << q;
                 if (dbg) {
                     int64_t rel = t0 + 8 * lane + q;
                     if (rel < (int64_t)a.P) { a.dbg_d[rel] = v[q + H]; a.dbg_S[rel] = s; }

@@ -58,6 +58,10 @@ extern "C" {
 #define AMPS_RECC_FLAG_TIME_KERNELS 0x1u /* record HIP events around every kernel (amps_recc_get_timing) */
 #define AMPS_RECC_FLAG_UNFUSED_WIDEBAND 0x4u /* channelizer seam: keep the channel-major intermediate in HBM (two kernels)
                                                instead of fusing the RECC front end behind the FFT; same results */
+#define AMPS_RECC_FLAG_SLICER_PRODUCT 0x8u /* IQ / wideband seams: slicer spec B of amps_recc_numerics.h (sign of
+                                               Im(x[n] conj(x[n-sps])), the telescoped form of discriminator + boxcar) */
+#define AMPS_RECC_FLAG_SLICER_SINE  0x10u /* IQ / wideband seams: slicer spec C (boxcar over Im(x[n] conj(x[n-1])): spec A without the
+                                               arctangent).  At most one of the two SLICER flags may be set */
 #define AMPS_RECC_FLAG_MAJORITY     0x2u /* decode mode "majority" instead of "reference" (SURVEY.md 8f.2), see below */
 
 /* message classes, the branches of lib/recc_decode_impl.cc:108-168 */

@@ -31,6 +31,39 @@
  *   g[n] = S[n] >= 0 ? 1 : 0                           binary_slicer_fb semantics (x >= 0 -> 1)
  *
  * Samples before the start of the stream are zero (x = 0 -> d = 0 -> g = 1).
+ *
+ * ---- slicer spec B, "product detector" (AMPS_RECC_FLAG_SLICER_PRODUCT) ----
+ * The boxcar of spec A sums the sps phase increments that end at n; that sum telescopes:
+ *     S[n] = sum_{k=n-sps+1..n} arg(x[k] conj(x[k-1]))  ==  arg(x[n] conj(x[n-sps]))   (mod 2 pi)
+ * so as long as |S[n]| < pi -- the phase advance over one Manchester symbol at the +-8 kHz AMPS
+ * deviation is 2.51 rad -- the slicer bit is the sign of Im(x[n] conj(x[n-sps])).  Spec B computes
+ * exactly that and nothing else (no arctangent, no reciprocal, no boxcar):
+ *
+ *   a = xi[n] * xr[n-sps]              binary32 products, round to nearest even
+ *   b = xr[n] * xi[n-sps]
+ *   s = a - b                          binary32 subtraction
+ *   g[n] = signbit(s) ? 0 : 1          (-0 counts as negative)
+ *   g[n] = 1 for the first sps samples of a stream (no partner yet), as in spec A
+ *
+ * Inputs must be finite with |x| < 2^60 (no overflow to inf - inf).  Spec B produces no FM-demod float
+ * intermediate; d[n] of spec A stays available through amps_recc_debug_demod on a spec-A handle.
+ * The two specs give the same bit wherever |S[n]| < pi and neither statistic is within rounding of
+ * zero; they differ on phase wraps (noise without carrier, low SNR: the margin to the wrap is only
+ * pi - 2.51 = 0.63 rad, so spec B loses bursts from ~12 dB SNR down while spec A holds to ~6 dB).
+ *
+ * ---- slicer spec C, "sine discriminator" (AMPS_RECC_FLAG_SLICER_SINE) ----
+ * Spec A with the arctangent left out: the discriminator output is the imaginary part of the
+ * conj-product itself, d'[n] = |x[n]| |x[n-1]| sin(phase increment), i.e. the classic polar
+ * discriminator; everything after it is spec A's boxcar, and only the sign leaves the kernel:
+ *
+ *   d'[n] = fmaf(xi, pr, -(xr*pi))                      the `im` of spec A, p = x[n-1]
+ *   S'[n] = spec A's ordered aligned-pair boxcar over d'[n-sps+1 .. n]
+ *   g[n]  = signbit(S'[n]) ? 0 : 1                      (x = 0 -> d' = +0 -> g = 1)
+ *
+ * No wrap can occur inside the window (every increment is below pi), low-amplitude (noisy) samples
+ * weigh less, and the cost is 2 flops per sample instead of ~25.  Measured on the synthetic bursts
+ * it decodes like spec A down to 8 dB SNR.  d' is not an FM-demod float in radians; the
+ * stated-tolerance intermediate of spec A stays available through amps_recc_debug_demod.
  */
 #ifndef AMPS_RECC_NUMERICS_H
 #define AMPS_RECC_NUMERICS_H
@@ -55,5 +88,10 @@
 #define AMPS_HALO_SAMPLES   1024   /* history recomputed at the head of every chunk / kept per push */
 #define AMPS_WORD_SAMPLES   64     /* samples per packed slicer word                              */
 #define AMPS_DEDUP_SYMBOLS  2      /* trigger hits closer than this many symbols form one run     */
+
+/* slicer specs */
+#define AMPS_SLICER_ATAN_BOXCAR 0  /* spec A: discriminator + boxcar (default)                      */
+#define AMPS_SLICER_PRODUCT     1  /* spec B: sign of Im(x[n] conj(x[n-sps]))                        */
+#define AMPS_SLICER_SINE        2  /* spec C: boxcar over Im(x[n] conj(x[n-1])), no arctangent       */
 
 #endif

@@ -63,6 +63,7 @@ struct orc_fused {
     uint8_t  trig[AMPS_RECC_TRIGGER_SYMS];
     int      tol;             /* accepted mismatching symbols of the 74 (0 = exact match = reference behaviour) */
     int      majority;        /* decode captures in the product's majority mode (AMPS_RECC_FLAG_MAJORITY)       */
+    int      slicer;          /* AMPS_SLICER_* of include/amps_recc_numerics.h                                   */
 };
 
 orc_fused_t *orc_fused_new(uint32_t channel, int sps)
@@ -79,6 +80,7 @@ void orc_fused_free(orc_fused_t *f)
 }
 void orc_fused_set_tolerance(orc_fused_t *f, int k) { f->tol = k < 0 ? 0 : k; }
 void orc_fused_set_majority(orc_fused_t *f, int on) { f->majority = on != 0; }
+void orc_fused_set_slicer(orc_fused_t *f, int spec) { f->slicer = spec; }
 size_t orc_fused_processed(const orc_fused_t *f) { return f->n_done; }
 const float *orc_fused_demod(const orc_fused_t *f) { return f->d; }
 const float *orc_fused_soft(const orc_fused_t *f) { return f->S; }
@@ -117,9 +119,22 @@ size_t orc_fused_push(orc_fused_t *f, const float *iq, size_t n, amps_recc_burst
     size_t P = ((f->n_in - f->n_done) / AMPS_WORD_SAMPLES) * AMPS_WORD_SAMPLES;
     size_t lo = f->n_done, hi = f->n_done + P;
     /* demod, boxcar, slicer */
+    if (f->slicer == AMPS_SLICER_PRODUCT) {
+        /* spec B: g[n] = !signbit(xi[n] xr[n-sps] - xr[n] xi[n-sps]); no demod float exists (d = 0, S = the statistic) */
+        for (size_t i = lo; i < hi; i++) {
+            f->d[i] = 0.0f;
+            if (i < (size_t)sps) { f->S[i] = 0.0f; f->g[i] = 1; continue; }   /* no partner yet: g = 1 by definition */
+            const float pr = f->x[2 * (i - sps)], pi_ = f->x[2 * (i - sps) + 1];
+            volatile float a = f->x[2 * i + 1] * pr, b = f->x[2 * i] * pi_;   /* volatile: two rounded products, never an fma */
+            const float s = a - b;
+            f->S[i] = s;
+            f->g[i] = signbit(s) ? 0 : 1;
+        }
+    } else
     for (size_t i = lo; i < hi; i++) {
         float pr = i ? f->x[2 * (i - 1)] : 0.0f, pi_ = i ? f->x[2 * (i - 1) + 1] : 0.0f;
-        f->d[i] = fm_phase(f->x[2 * i], f->x[2 * i + 1], pr, pi_);
+        f->d[i] = f->slicer == AMPS_SLICER_SINE ? fmaf(f->x[2 * i + 1], pr, -(f->x[2 * i] * pi_))     /* spec C: Im(x conj(p)) = |x||p| sin(d) */
+                                 : fm_phase(f->x[2 * i], f->x[2 * i + 1], pr, pi_);
         /* boxcar per the numeric spec: aligned pair sums, oldest to newest */
         float s = 0.0f;
         int first = 1;
@@ -137,7 +152,7 @@ size_t orc_fused_push(orc_fused_t *f, const float *iq, size_t n, amps_recc_burst
             if (first) { s = v; first = 0; } else s = s + v;
         }
         f->S[i] = s;
-        f->g[i] = s >= 0.0f ? 1 : 0;
+        f->g[i] = f->slicer == AMPS_SLICER_SINE ? (signbit(s) ? 0 : 1) : (s >= 0.0f ? 1 : 0);
     }
     /* 74-symbol trigger test ending at sample i: at most `tol` symbols may differ (tol = 0: the reference's exact
      * memmem, lib/recc_impl.cc:118) */

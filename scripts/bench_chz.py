@@ -1,0 +1,28 @@
+"""Microbench of the wideband seam's filter-bank kernel: ms per 1 GiB push for each slicer spec (HIP events).
+usage (GPU box): [AMPS_RECC_LIB=variant.so] python scripts/bench_chz.py [reps]"""
+import sys
+import torch
+sys.path.insert(0, ".")
+from gr_amps_amd import capi
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+NW = 1 << 27
+g = torch.Generator(device="cuda")
+g.manual_seed(1)
+x = torch.view_as_complex(torch.randn(NW, 2, device="cuda", generator=g) * 0.5)
+torch.cuda.synchronize()
+wb = {"channels": 1024, "decim": 512, "taps_per_branch": 8, "first_channel": 96}
+for spec in ("atan", "sine", "product"):
+    r = capi.Recc(n_channels=832, sps=3, max_samples=NW // 512 + 8, max_bursts=4096, time_kernels=True, wideband=wb, slicer=spec)
+    for _ in range(40):
+        r.push_wideband(x)
+        r.drain()
+    r.timing(reset=True)
+    for _ in range(reps):
+        r.push_wideband(x)
+        r.drain()
+    t = r.timing()
+    print("%-8s chz %.4f ms  bits %.4f  resolve %.4f  decode %.4f" % (
+        spec, t["ms_channelizer"] / t["launches_channelizer"], t["ms_front"] / max(1, t["launches_front"]),
+        t["ms_resolve"] / reps, t["ms_decode"] / reps), flush=True)
+    r.close()
