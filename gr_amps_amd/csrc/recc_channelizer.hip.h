@@ -273,21 +273,38 @@ __device__ __forceinline__ void chz_p2(cf2 *A, const cf2 *tab, int lane)
 }
 
 // pass 3, radix 4, p = 64: u[r] = B[t + 256 r] e^{-2 pi i r k / 256}, k = t & 63; C[4 (t - k) + k + 64 r] = X[r]
-__device__ __forceinline__ void chz_p3(const cf2 *A, cf2 *Cb, const cf2 (&tw)[3], int t)
+// The four frames of a batch are independent: all sixteen LDS reads are issued before the first butterfly (the compiler
+// otherwise keeps read -> wait -> butterfly per frame, four exposed LDS latencies per pass).
+__device__ __forceinline__ void chz_p3_batch(const cf2 *A, cf2 *Cb, const cf2 (&tw)[3], int t)
 {
     const cf2 *src = A + cpad(t);                               // cpad(t + 256 r) = cpad(t) + 272 r
-    cf2 o[4];
-    dft4(src[0], cmul(src[272], tw[0]), cmul(src[544], tw[1]), cmul(src[816], tw[2]), o);
+    cf2 u[CHZ_BATCH][4];
+#pragma unroll
+    for (int g = 0; g < CHZ_BATCH; g++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) u[g][r] = src[g * CHZ_FB + 272 * r];
     const int k = t & 63;
     cf2 *d = Cb + cpad(4 * (t - k) + k);                        // cpad(j + 64 r) = cpad(j) + 68 r
-    d[0] = o[0]; d[68] = o[1]; d[136] = o[2]; d[204] = o[3];
+#pragma unroll
+    for (int g = 0; g < CHZ_BATCH; g++) {
+        cf2 o[4];
+        dft4(u[g][0], cmul(u[g][1], tw[0]), cmul(u[g][2], tw[1]), cmul(u[g][3], tw[2]), o);
+        d[g * CHZ_FB] = o[0]; d[g * CHZ_FB + 68] = o[1]; d[g * CHZ_FB + 136] = o[2]; d[g * CHZ_FB + 204] = o[3];
+    }
 }
 
-// pass 4, radix 4, p = 256: bins t + 256 r of the frame
-__device__ __forceinline__ void chz_p4(const cf2 *Cb, const cf2 (&tw)[3], int t, cf2 (&y)[4])
+// pass 4, radix 4, p = 256: bins t + 256 r of the frame; `u` = the frame's four inputs (read by chz_p4_load)
+__device__ __forceinline__ void chz_p4_load(const cf2 *Cb, int t, cf2 (&u)[CHZ_BATCH][4])
 {
     const cf2 *src = Cb + cpad(t);
-    dft4(src[0], cmul(src[272], tw[0]), cmul(src[544], tw[1]), cmul(src[816], tw[2]), y);
+#pragma unroll
+    for (int g = 0; g < CHZ_BATCH; g++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) u[g][r] = src[g * CHZ_FB + 272 * r];
+}
+__device__ __forceinline__ void chz_p4(const cf2 (&u)[4], const cf2 (&tw)[3], cf2 (&y)[4])
+{
+    dft4(u[0], cmul(u[1], tw[0]), cmul(u[2], tw[1]), cmul(u[3], tw[2]), y);
 }
 
 // per-thread constants of the pipeline
@@ -391,11 +408,14 @@ __global__ __launch_bounds__(256) void chz_pfb_fft_kernel(ChzArgs a)
             __syncthreads();
             chz_p2(bufA + wv * CHZ_FB, tab, lane);
             __syncthreads();
-#pragma unroll
-            for (int g = 0; g < CHZ_BATCH; g++) chz_p3(bufA + g * CHZ_FB, bufC + g * CHZ_FB, R.tw3, t);
+            chz_p3_batch(bufA, bufC, R.tw3, t);
             __syncthreads();
+            {
+                cf2 u4[CHZ_BATCH][4];
+                chz_p4_load(bufC, t, u4);
 #pragma unroll
-            for (int g = 0; g < CHZ_BATCH; g++) chz_p4(bufC + g * CHZ_FB, R.tw4, t, acc[hb + g]);
+                for (int g = 0; g < CHZ_BATCH; g++) chz_p4(u4[g], R.tw4, acc[hb + g]);
+            }
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -526,37 +546,39 @@ __global__ __launch_bounds__(256, P <= 8 ? 2 : 1) void chz_fused_kernel(ChzArgs 
         __syncthreads();
         chz_p2(bufA + wv * CHZ_FB, tab, lane);
         __syncthreads();
-#pragma unroll
-        for (int g = 0; g < CHZ_BATCH; g++) chz_p3(bufA + g * CHZ_FB, bufC + g * CHZ_FB, R.tw3, t);
+        chz_p3_batch(bufA, bufC, R.tw3, t);
         __syncthreads();
+        cf2 u4[CHZ_BATCH][4];
+        chz_p4_load(bufC, t, u4);
         if constexpr (SL == AMPS_SLICER_PRODUCT) {
             // frame g pairs with frame g - 3: frames 0..2 with frames 1..3 of the previous batch, frame 3 with frame 0
             cf2 y0[4];
-            chz_p4(bufC, R.tw4, t, y0);
+            chz_p4(u4[0], R.tw4, y0);
             chz_slice_prod(y0, hist[0], gw);
-            chz_p4(bufC + CHZ_FB, R.tw4, t, hist[0]);             // frame 1 takes the place of the value it replaces
+            chz_p4(u4[1], R.tw4, hist[0]);                        // frame 1 takes the place of the value it replaces
             chz_slice_prod(hist[0], hist[1], gw);
-            chz_p4(bufC + 2 * CHZ_FB, R.tw4, t, hist[1]);
+            chz_p4(u4[2], R.tw4, hist[1]);
             chz_slice_prod(hist[1], hist[2], gw);
-            chz_p4(bufC + 3 * CHZ_FB, R.tw4, t, hist[2]);
+            chz_p4(u4[3], R.tw4, hist[2]);
             chz_slice_prod(hist[2], y0, gw);
         } else if constexpr (SL == AMPS_SLICER_SINE) {
-            const bool pre = a.stream_start && f < 0;             // frames before the stream are exactly +0 (the FFT of zeros may hold -0)
 #pragma unroll
             for (int g = 0; g < CHZ_BATCH; g++) {
                 cf2 y[4];
-                chz_p4(bufC + g * CHZ_FB, R.tw4, t, y);
-                if (pre) {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) y[j] = (cf2){ 0.f, 0.f };
-                }
+                chz_p4(u4[g], R.tw4, y);
                 if (g & 1) chz_bins_sine<1>(y, prev, d1, d2, gw); else chz_bins_sine<0>(y, prev, d1, d2, gw);
+            }
+            if (a.stream_start && f < 0) {                        // frames before the stream are exactly +0 (the FFT of zeros may hold -0):
+                asm volatile("" ::: "memory");                    // the state they leave is all zeros (a real branch, once per launch)
+#pragma unroll
+                for (int j = 0; j < 4; j++) { prev[j] = (cf2){ 0.f, 0.f }; gw[j] = 0u; }
+                d1[0] = d1[1] = d2[0] = d2[1] = (f2){ 0.f, 0.f };
             }
         } else {
 #pragma unroll
         for (int g = 0; g < CHZ_BATCH; g++) {
             cf2 y[4];
-            chz_p4(bufC + g * CHZ_FB, R.tw4, t, y);
+            chz_p4(u4[g], R.tw4, y);
             if (g & 1) chz_bins<1>(y, prev, d1, d2, gw); else chz_bins<0>(y, prev, d1, d2, gw);
         }
         }
@@ -569,6 +591,406 @@ __global__ __launch_bounds__(256, P <= 8 ? 2 : 1) void chz_fused_kernel(ChzArgs 
                 if (SL == AMPS_SLICER_PRODUCT && a.stream_start && f + 3 == 31) word |= 7u;   // no partner yet: g = 1
                 if (ch < a.n_channels) ((uint32_t *)(a.gring + (uint64_t)ch * a.ring_words))[(n >> 5) & mask32] = word;
             }
+        }
+    }
+}
+
+// The delay lines as a register RING (12-wave kernel): branch jb keeps P + 4 slots; at a half-step with rotation BASE the
+// logical element i of the old {delay line, new samples} view is ring[jb][(BASE + i) % (P + 4)]: elements 0..P-1 the delay
+// line, P and P+1 the samples of this half-step's four frames, P+2 and P+3 those of the NEXT half-step (in flight).  After
+// the fold the two oldest slots are dead and receive the loads of the half-step after next, and BASE advances by two: no
+// register ever moves (the 4-wave kernels shift 32 register pairs per four frames), and a load has two half-steps to land.
+// The half-step loop is unrolled over the ring's period of (P + 4) / 2 rotations.
+template <int P, int PAR, int SA, int SB, int BASE>
+__device__ __forceinline__ void chz_fold_p1_ring(const cf2 (&ring)[4][P + 4], const cf2 (&coef)[4][P / 2], cf2 *A, int t)
+{
+    constexpr int R = P + 4;
+    constexpr int SW = 2 * ((PAR + 1) & 1);
+    cf2 x[4];
+#pragma unroll
+    for (int jb = 0; jb < 4; jb++) {
+        const int sh = jb < 2 ? SA : SB;
+        cf2 s = { 0.f, 0.f };
+#pragma unroll
+        for (int q = 0; q < P; q += 2) {                            // taps q, q+1 share one coefficient pair
+            s = fma_lo(ring[jb][(BASE + sh + q) % R], coef[jb ^ SW][q / 2], s);
+            s = fma_hi(ring[jb][(BASE + sh + q + 1) % R], coef[jb ^ SW][q / 2], s);
+        }
+        x[jb] = s;
+    }
+    cf2 o[4];
+    dft4(x[0], x[1], x[2], x[3], o);                            // radix 4, p = 1: no twiddles
+    cf2 *d = A + cpad(4 * t);
+#if CHZ_EXP == 7 || CHZ_EXP == 8
+    if (o[0].x == 1.2345f) d[0] = o[0] + o[1] + o[2] + o[3];      // timing experiment: keep the arithmetic, drop the LDS stores
+#else
+    d[0] = o[0]; d[1] = o[1]; d[2] = o[2]; d[3] = o[3];
+#endif
+}
+// Two frames at a time: eight independent accumulator chains (2 frames x 4 branches), two taps per asm block.  Measured
+// (scripts/ubench_pk2.hip): a lone wave on a SIMD issues v_pk_fma_f32 with three distinct register-pair sources every 7.1
+// cycles with 4 chains and one-instruction asm statements (the compiler puts an s_nop behind every group of dependent asm
+// statements -- it counts an asm statement as zero wait states -- and a lone wave pays a full issue slot for it), 6.2 with 8
+// chains; inside one asm block there is nothing to pad, and a dependent v_pk_fma is eight instructions away.
+#define CHZ_FMA_LO(d, x, c) "v_pk_fma_f32 %" #d ", %" #x ", %" #c ", %" #d " op_sel_hi:[1,0,1]\n\t"
+#define CHZ_FMA_HI(d, x, c) "v_pk_fma_f32 %" #d ", %" #x ", %" #c ", %" #d " op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+#define CHZ_MUL_LO(d, x, c) "v_pk_mul_f32 %" #d ", %" #x ", %" #c " op_sel_hi:[1,0]\n\t"
+// acc[f][jb] (+)= x0[f][jb] * c[jb ^ SW_f].lo ; then += x1[f][jb] * c[jb ^ SW_f].hi   (SW_0 = 2, SW_1 = 0: frame 0 has even parity)
+template <bool FIRST>
+__device__ __forceinline__ void chz_fold_taps2(cf2 (&acc)[2][4], const cf2 (&x0)[2][4], const cf2 (&x1)[2][4], const cf2 (&c)[4])
+{
+    // operands: 0..7 acc[f][jb] (f major), 8..15 x0, 16..23 x1, 24..27 c[0..3]
+    if constexpr (FIRST) {
+        asm(CHZ_MUL_LO(0, 8, 26) CHZ_MUL_LO(1, 9, 27) CHZ_MUL_LO(2, 10, 24) CHZ_MUL_LO(3, 11, 25)
+            CHZ_MUL_LO(4, 12, 24) CHZ_MUL_LO(5, 13, 25) CHZ_MUL_LO(6, 14, 26) CHZ_MUL_LO(7, 15, 27)
+            CHZ_FMA_HI(0, 16, 26) CHZ_FMA_HI(1, 17, 27) CHZ_FMA_HI(2, 18, 24) CHZ_FMA_HI(3, 19, 25)
+            CHZ_FMA_HI(4, 20, 24) CHZ_FMA_HI(5, 21, 25) CHZ_FMA_HI(6, 22, 26) CHZ_FMA_HI(7, 23, 27)
+            : "=&v"(acc[0][0]), "=&v"(acc[0][1]), "=&v"(acc[0][2]), "=&v"(acc[0][3]), "=&v"(acc[1][0]), "=&v"(acc[1][1]), "=&v"(acc[1][2]), "=&v"(acc[1][3])
+            : "v"(x0[0][0]), "v"(x0[0][1]), "v"(x0[0][2]), "v"(x0[0][3]), "v"(x0[1][0]), "v"(x0[1][1]), "v"(x0[1][2]), "v"(x0[1][3]),
+              "v"(x1[0][0]), "v"(x1[0][1]), "v"(x1[0][2]), "v"(x1[0][3]), "v"(x1[1][0]), "v"(x1[1][1]), "v"(x1[1][2]), "v"(x1[1][3]),
+              "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]));
+    } else {
+        asm(CHZ_FMA_LO(0, 8, 26) CHZ_FMA_LO(1, 9, 27) CHZ_FMA_LO(2, 10, 24) CHZ_FMA_LO(3, 11, 25)
+            CHZ_FMA_LO(4, 12, 24) CHZ_FMA_LO(5, 13, 25) CHZ_FMA_LO(6, 14, 26) CHZ_FMA_LO(7, 15, 27)
+            CHZ_FMA_HI(0, 16, 26) CHZ_FMA_HI(1, 17, 27) CHZ_FMA_HI(2, 18, 24) CHZ_FMA_HI(3, 19, 25)
+            CHZ_FMA_HI(4, 20, 24) CHZ_FMA_HI(5, 21, 25) CHZ_FMA_HI(6, 22, 26) CHZ_FMA_HI(7, 23, 27)
+            : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3])
+            : "v"(x0[0][0]), "v"(x0[0][1]), "v"(x0[0][2]), "v"(x0[0][3]), "v"(x0[1][0]), "v"(x0[1][1]), "v"(x0[1][2]), "v"(x0[1][3]),
+              "v"(x1[0][0]), "v"(x1[0][1]), "v"(x1[0][2]), "v"(x1[0][3]), "v"(x1[1][0]), "v"(x1[1][1]), "v"(x1[1][2]), "v"(x1[1][3]),
+              "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]));
+    }
+}
+// frames FA, FA+1 of a half-step (FA = 0: tap windows start at SA = 1 / SB = 0 and 1 / 1; FA = 2: 2 / 1 and 2 / 2), then the
+// radix-4 pass 1 of both -> A[FA], A[FA+1]
+template <int P, int BASE, int FA>
+__device__ __forceinline__ void chz_fold2_ring(const cf2 (&ring)[4][P + 4], const cf2 (&coef)[4][P / 2], cf2 *bufA, int t)
+{
+    constexpr int R = P + 4;
+    constexpr int S[2][2] = { { FA == 0 ? 1 : 2, FA == 0 ? 0 : 1 }, { FA == 0 ? 1 : 2, FA == 0 ? 1 : 2 } };   // [frame][jb >= 2]
+    cf2 acc[2][4];
+#pragma unroll
+    for (int q = 0; q < P; q += 2) {
+        cf2 x0[2][4], x1[2][4], c[4];
+#pragma unroll
+        for (int f = 0; f < 2; f++)
+#pragma unroll
+            for (int jb = 0; jb < 4; jb++) {
+                x0[f][jb] = ring[jb][(BASE + S[f][jb >> 1] + q) % R];
+                x1[f][jb] = ring[jb][(BASE + S[f][jb >> 1] + q + 1) % R];
+            }
+#pragma unroll
+        for (int j = 0; j < 4; j++) c[j] = coef[j][q / 2];
+        if (q == 0) chz_fold_taps2<true>(acc, x0, x1, c); else chz_fold_taps2<false>(acc, x0, x1, c);
+    }
+#pragma unroll
+    for (int f = 0; f < 2; f++) {
+        cf2 o[4];
+        dft4(acc[f][0], acc[f][1], acc[f][2], acc[f][3], o);     // radix 4, p = 1: no twiddles
+        cf2 *d = bufA + (FA + f) * CHZ_FB + cpad(4 * t);
+#if CHZ_EXP == 7 || CHZ_EXP == 8
+        if (o[0].x == 1.2345f) d[0] = o[0] + o[1] + o[2] + o[3];  // timing experiment: keep the arithmetic, drop the LDS stores
+#else
+        d[0] = o[0]; d[1] = o[1]; d[2] = o[2]; d[3] = o[3];
+#endif
+    }
+}
+template <int P, int BASE>
+__device__ __forceinline__ void chz_fold_half_ring(const cf2 (&ring)[4][P + 4], const cf2 (&coef)[4][P / 2], cf2 *bufA, int t)
+{
+    chz_fold2_ring<P, BASE, 0>(ring, coef, bufA, t);
+    chz_fold2_ring<P, BASE, 2>(ring, coef, bufA, t);
+}
+// the two samples frame F + g brings for this thread go to branches 2 (g & 1) + {0, 1}, logical element ELEM + (g >> 1).
+// FAST (the four frames lie inside the new block): the eight loads are issued as inline asm, so that the compiler does not
+// track them -- its own bookkeeping puts `s_waitcnt vmcnt(0)` behind every barrier of the loop (the fast / generic join
+// makes it conservative), which drains the loads issued a moment ago and halves the lead a load has.  The fold waits with
+// chz_ring_wait instead: vmcnt(8) = "everything but the eight youngest loads", i.e. exactly the loads of the previous
+// half-step stay in flight.  The generic path (carry, zero padding: first and last half-steps of a launch) uses ordinary
+// loads and drains them before it returns, so vmcnt(8) is right after either path.
+template <int P, int BASE, int ELEM, bool FAST>
+__device__ __forceinline__ void chz_load_half_ring(cf2 (&ring)[4][P + 4], const ChzIn &in, int64_t F, int t)
+{
+    constexpr int R = P + 4;
+    if constexpr (FAST) {
+        const float2 *p = in.block + (F * CHZ_D - in.lead) + t;
+#pragma unroll
+        for (int g = 0; g < CHZ_BATCH; g++) {
+            const float2 *q = p + g * CHZ_D;
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(ring[2 * (g & 1)][(BASE + ELEM + (g >> 1)) % R]) : "v"(q));
+            asm volatile("global_load_dwordx2 %0, %1, off offset:2048" : "=v"(ring[2 * (g & 1) + 1][(BASE + ELEM + (g >> 1)) % R]) : "v"(q));
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < CHZ_BATCH; g++)
+            in.template frame<false>(F + g, t, ring[2 * (g & 1)][(BASE + ELEM + (g >> 1)) % R], ring[2 * (g & 1) + 1][(BASE + ELEM + (g >> 1)) % R]);
+        // a use of all eight destinations: the compiler drains its loads HERE and carries no pending load out of this path
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[0][(BASE + ELEM) % R]), "+v"(ring[1][(BASE + ELEM) % R]), "+v"(ring[2][(BASE + ELEM) % R]),
+                     "+v"(ring[3][(BASE + ELEM) % R]), "+v"(ring[0][(BASE + ELEM + 1) % R]), "+v"(ring[1][(BASE + ELEM + 1) % R]),
+                     "+v"(ring[2][(BASE + ELEM + 1) % R]), "+v"(ring[3][(BASE + ELEM + 1) % R]) :: "memory");
+    }
+}
+// before a fold: the samples of logical elements P and P+1 (loaded two half-steps ago) have arrived; the empty asm makes
+// every use of those registers depend on the wait
+template <int P, int BASE>
+__device__ __forceinline__ void chz_ring_wait(cf2 (&ring)[4][P + 4])
+{
+    constexpr int R = P + 4;
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("" : "+v"(ring[0][(BASE + P) % R]), "+v"(ring[1][(BASE + P) % R]), "+v"(ring[2][(BASE + P) % R]), "+v"(ring[3][(BASE + P) % R]),
+                      "+v"(ring[0][(BASE + P + 1) % R]), "+v"(ring[1][(BASE + P + 1) % R]), "+v"(ring[2][(BASE + P + 1) % R]), "+v"(ring[3][(BASE + P + 1) % R]));
+}
+
+// ---- the 12-wave pipeline (P = 8): fold waves and FFT waves ----
+// The 4-wave kernels above keep every per-thread state of the filter bank in ONE set of waves: delay lines, coefficients and
+// input prefetch (112 VGPRs) next to the radix-16 temporaries (64) and the twiddles -- 222 VGPRs, two waves per SIMD, and a
+// 70 KB exchange buffer per workgroup; half of the issue slots stay empty while both waves of a SIMD sit in LDS latency or in
+// one of the three barriers per four frames.  Here one 768-thread workgroup owns a CU and splits the ROLES between waves:
+//   waves 0..3   "fold":  thread t keeps branches t + 256 j in registers (exactly as above), folds a frame and runs the
+//                radix-4 pass 1 on its own registers -> bufA[next][frame].  Pure VALU + prefetched global loads.
+//   waves 4..11  "FFT":   wave w owns frame w of a batch of EIGHT outright and runs the rest of the FFT wave-privately, in
+//                place: pass 2 (radix 16, p = 4) as above, then ONE more radix-16 pass (p = 64: lane i takes points
+//                i + 64 r, twiddles W_1024^{r i} from registers) which leaves the frame in natural order.  After a barrier
+//                thread u reads bins u and u + 512 of all eight frames: a lane owns the same two channels for ever, and
+//                the slicer state is two small register sets.
+// The fold waves work one batch ahead into the other half of a double buffer (2 x 8 frames = 136 KB of LDS), so a batch
+// costs two workgroup barriers per EIGHT frames instead of six, the fold's VALU stream fills the issue slots the FFT waves
+// leave while they wait for LDS, and both roles fit 168 VGPRs: three waves per SIMD.  FFT-1024 = 4 x 16 x 16 needs one
+// LDS round trip less than 4 x 16 x 4 x 4.  The unfused form is the same kernel with a different epilogue (MODE_IQ: the
+// bins go to the channel-major block as 64-byte runs), so fused and unfused forms stay bit-identical by construction.
+#ifndef CHZ_PRIO
+#define CHZ_PRIO 0
+#endif
+#ifndef CHZ_EXP
+#define CHZ_EXP 0            // timing experiments (pieces compiled out; results are wrong): never set in a shipped build
+#endif
+constexpr int CHZ_NB = 8;                                        // frames per batch
+constexpr int CHZ12_IQ = -1;                                     // MODE: write the channel-major block; >= 0: AMPS_SLICER_* fused behind the FFT
+
+// pass 3 of the 4 x 16 x 16 factorisation, radix 16, p = 64, one frame per wave, in place:
+//   lane i: u[r] = A[i + 64 r] W_1024^{r i};  A[i + 64 r] = DFT16(u)[r]        (natural bin order)
+__device__ __forceinline__ void chz_p34(cf2 *A, const cf2 (&tw)[15], int lane)
+{
+    cf2 u[16];
+    cf2 *src = A + cpad(lane);                                  // cpad(lane + 64 r) = cpad(lane) + 68 r
+#pragma unroll
+    for (int r = 0; r < 16; r++) u[r] = src[68 * r];
+#pragma unroll
+    for (int r = 1; r < 16; r++) u[r] = cmul(u[r], tw[r - 1]);
+    cf2 v[4][4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) dft4(u[b], u[4 + b], u[8 + b], u[12 + b], v[b]);
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
+    v[1][1] = cmul_s(v[1][1], (cf2){ C1, -S1 });
+    v[1][2] = cmul_s(v[1][2], (cf2){ R2, -R2 });
+    v[1][3] = cmul_s(v[1][3], (cf2){ S1, -C1 });
+    v[2][1] = cmul_s(v[2][1], (cf2){ R2, -R2 });
+    v[2][2] = mul_mi(v[2][2]);
+    v[2][3] = cmul_s(v[2][3], (cf2){ -R2, -R2 });
+    v[3][1] = cmul_s(v[3][1], (cf2){ S1, -C1 });
+    v[3][2] = cmul_s(v[3][2], (cf2){ -R2, -R2 });
+    v[3][3] = cmul_s(v[3][3], (cf2){ -C1, S1 });
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        cf2 X[4];
+        dft4(v[0][c], v[1][c], v[2][c], v[3][c], X);
+#pragma unroll
+        for (int d = 0; d < 4; d++) src[68 * (c + 4 * d)] = X[d];
+    }
+}
+
+// slicer state of the two bins a lane of the FFT role owns (specs of include/amps_recc_numerics.h)
+template <int SL> struct ChzSlice2 {
+    cf2 prev[2];             // spec A / C: the bins one frame earlier
+    f2 d1, d2;               // spec A / C: the last two discriminator outputs of (bin 0, bin 1)
+    cf2 h1[2], h2[2], h3[2]; // spec B: the bins one, two and three frames earlier
+    uint32_t gw[2];          // spec A: slicer bits, newest at bit 31; specs B / C: SIGN bits, newest at bit 0
+    __device__ __forceinline__ void reset()
+    {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            prev[j] = h1[j] = h2[j] = h3[j] = (cf2){ 0.f, 0.f };
+            gw[j] = SL == AMPS_SLICER_ATAN_BOXCAR ? ~0u : 0u;     // "ones before the stream" in either representation
+        }
+        d1 = d2 = (f2){ 0.f, 0.f };
+    }
+    template <int PAR> __device__ __forceinline__ void step(const cf2 (&y)[2])   // PAR = parity of the absolute frame index
+    {
+        if constexpr (SL == AMPS_SLICER_PRODUCT) {
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                cf2 m;                                              // (yr * pi, yi * pr): the partner's halves swapped by op_sel
+                asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(m) : "v"(y[j]), "v"(h3[j]));
+                gw[j] = __builtin_amdgcn_alignbit(gw[j], __float_as_uint(m.y - m.x), 31);
+                h3[j] = h2[j]; h2[j] = h1[j]; h1[j] = y[j];
+            }
+        } else {
+            f2 d;
+            if constexpr (SL == AMPS_SLICER_SINE)
+                d = (f2){ __builtin_fmaf(y[0].y, prev[0].x, -(y[0].x * prev[0].y)), __builtin_fmaf(y[1].y, prev[1].x, -(y[1].x * prev[1].y)) };
+            else d = fm_phase_two(y[0], prev[0], y[1], prev[1]);
+            // window [n-2, n]: n even -> (d[n-2] + d[n-1]) + d[n];  n odd -> d[n-2] + (d[n-1] + d[n])
+            const f2 s = PAR == 0 ? (d2 + d1) + d : d2 + (d1 + d);
+            if constexpr (SL == AMPS_SLICER_SINE) {
+                gw[0] = __builtin_amdgcn_alignbit(gw[0], __float_as_uint(s.x), 31);
+                gw[1] = __builtin_amdgcn_alignbit(gw[1], __float_as_uint(s.y), 31);
+            } else {
+                gw[0] = __builtin_amdgcn_alignbit(s.x >= 0.0f ? 1u : 0u, gw[0], 1);
+                gw[1] = __builtin_amdgcn_alignbit(s.y >= 0.0f ? 1u : 0u, gw[1], 1);
+            }
+            d2 = d1; d1 = d;
+            prev[0] = y[0]; prev[1] = y[1];
+        }
+    }
+    __device__ __forceinline__ uint32_t word(int j) const { return SL == AMPS_SLICER_ATAN_BOXCAR ? gw[j] : ~__builtin_bitreverse32(gw[j]); }
+};
+
+template <int P, int MODE>
+__global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
+{
+    constexpr int M = CHZ_M, D = CHZ_D, NB = CHZ_NB;
+    constexpr bool IQ = MODE == CHZ12_IQ;
+    constexpr int SL = IQ ? AMPS_SLICER_ATAN_BOXCAR : MODE;
+    __shared__ cf2 bufA[2][NB * CHZ_FB];
+    __shared__ cf2 tab[64];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int64_t f0 = (int64_t)blockIdx.x * a.frames_per_wg;   // multiple of 64
+    if (f0 >= (int64_t)a.nframes) return;
+    int64_t f1 = f0 + a.frames_per_wg; if (f1 > (int64_t)a.nframes) f1 = a.nframes;
+    // the slicer state of every bin is rebuilt by one pre-roll batch; its first four frames may reach behind the carry
+    // (zeros): they only prime the delay lines for the last four, which are exact (the carry holds L - D + 4 D samples)
+    const int64_t fs = IQ ? f0 : f0 - NB;
+    const int nbatch = (int)((f1 - fs + NB - 1) / NB);
+    if (tid < 64) tab[tid] = chz_twiddle((tid >> 2) * (tid & 3), 64);   // tab[4 r + k]
+
+    // time step s: the fold waves produce batch s into bufA[s & 1] while the FFT waves consume batch s - 1 from the other
+    // half; both roles pass the same two barriers per step
+    if (wave < 4) {
+        // ------------------------------------------------------------------ fold role
+        const int t = tid;
+        const ChzIn in{ a.block, a.carry, (int64_t)a.hist, (int64_t)a.carry_len - (int64_t)a.hist, (int64_t)a.carry_len, (int64_t)a.nsamp };
+        cf2 coef[4][P / 2];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int q = 0; q < P; q += 2) coef[j][q / 2] = (cf2){ a.taps[t + 256 * j + q * M], a.taps[t + 256 * j + (q + 1) * M] };
+        cf2 ring[4][P + 4];                                       // delay lines + the inputs of this and the next half-step
+        {
+            const int64_t vend = fs * D;                          // multiple of M (fs is even)
+#pragma unroll
+            for (int jb = 0; jb < 4; jb++) {
+                const int64_t vlast = vend - M + (t + 256 * jb);
+#pragma unroll
+                for (int q = 0; q < P; q++) ring[jb][q] = in.generic(vlast - (int64_t)M * (P - 1 - q));
+            }
+        }
+        chz_load_half_ring<P, 0, P, false>(ring, in, fs, t);
+        chz_load_half_ring<P, 0, P + 2, false>(ring, in, fs + CHZ_BATCH, t);
+        __syncthreads();                                          // tab
+        // one half-step = four frames: fold them, then load the frames of the half-step after next into the two slots that
+        // just died.  A load has eight frames (~4 us) to arrive: with four frames of lead, as in the 4-wave kernels, the fold
+        // waves were the critical path (4 waves x 8 loads x 512 B = 16 KB in flight per CU do not cover the HBM latency under
+        // load: fold + slicer alone ran 0.39 ms per GiB, the FFT waves alone 0.31).
+        auto half_step = [&](auto basec, int sidx, int half) {
+            constexpr int BASE = decltype(basec)::value;
+            if (sidx < nbatch) {
+                const int64_t F = fs + (int64_t)NB * sidx + CHZ_BATCH * half;
+                cf2 *dst = bufA[sidx & 1] + CHZ_BATCH * half * CHZ_FB;
+                chz_ring_wait<P, BASE>(ring);
+#if CHZ_EXP != 3
+                chz_fold_half_ring<P, BASE>(ring, coef, dst, t);
+#endif
+#if CHZ_EXP != 6 && CHZ_EXP != 8
+                if (in.batch_in_block(F + NB)) chz_load_half_ring<P, BASE, P + 4, true>(ring, in, F + NB, t);
+                else chz_load_half_ring<P, BASE, P + 4, false>(ring, in, F + NB, t);   // generic: zero beyond the data
+#endif
+            }
+            __syncthreads();
+        };
+        constexpr int PERIOD = (P + 4) / 2;                       // half-steps until the ring is back where it started (6)
+        static_assert(PERIOD == 6, "the unrolled loop below is written for P = 8");
+        for (int s = 0; s <= nbatch; s += 3) {                    // three time steps = six half-steps = one ring period
+            half_step(std::integral_constant<int, 0>{}, s, 0);
+            half_step(std::integral_constant<int, 2>{}, s, 1);
+            if (s + 1 > nbatch) break;
+            half_step(std::integral_constant<int, 4>{}, s + 1, 0);
+            half_step(std::integral_constant<int, 6>{}, s + 1, 1);
+            if (s + 2 > nbatch) break;
+            half_step(std::integral_constant<int, 8>{}, s + 2, 0);
+            half_step(std::integral_constant<int, 10>{}, s + 2, 1);
+        }
+    } else {
+        // ------------------------------------------------------------------ FFT role
+        const int u = tid - 256;                                  // 0..511: owns bins u and u + 512
+        const int wf = wave - 4;                                  // frame of the batch this wave transforms
+#if CHZ_PRIO
+        __builtin_amdgcn_s_setprio(CHZ_PRIO);                     // the FFT waves are the critical path of a time step
+#endif
+        cf2 tw34[15];
+#pragma unroll
+        for (int r = 1; r < 16; r++) tw34[r - 1] = chz_twiddle(r * lane, 1024);
+        ChzSlice2<SL> S;
+        S.reset();
+        const uint64_t mask32 = 2ull * a.ring_words - 1;
+        uint32_t ch[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) ch[j] = ((uint32_t)(u + 512 * j) - a.first_bin) & (M - 1);
+        __syncthreads();                                          // tab
+        for (int s = 0; s <= nbatch; s++) {
+            cf2 *A = bufA[(s - 1) & 1];
+            if (s >= 1) {
+                cf2 *Af = A + wf * CHZ_FB;
+#if CHZ_EXP != 2 && CHZ_EXP != 4 && CHZ_EXP < 6
+                chz_p2(Af, tab, lane);
+#endif
+#if CHZ_EXP != 2 && CHZ_EXP != 5 && CHZ_EXP < 6
+                chz_p34(Af, tw34, lane);
+#endif
+            }
+            __syncthreads();
+            if (s >= 1) {
+                const int64_t F = fs + (int64_t)NB * (s - 1);     // first frame of the batch (multiple of 8)
+                cf2 y[NB][2];
+#pragma unroll
+                for (int g = 0; g < NB; g++) { y[g][0] = A[g * CHZ_FB + cpad(u)]; y[g][1] = A[g * CHZ_FB + cpad(u + 512)]; }
+                if constexpr (IQ) {
+                    // eight frames of a bin leave as one 64-byte run of the channel-major block
+                    const int ng = (int)(f1 - F < (int64_t)NB ? f1 - F : (int64_t)NB);
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        if (ch[j] < a.n_channels) {
+                            float2 *dstp = a.out + (uint64_t)ch[j] * a.ld + F;
+                            if (ng == NB) {
+#pragma unroll
+                                for (int e = 0; e < NB; e += 2)
+                                    *(float4 *)(dstp + e) = make_float4(y[e][j].x, y[e][j].y, y[e + 1][j].x, y[e + 1][j].y);
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < NB; e++)
+                                    if (e < ng) dstp[e] = make_float2(y[e][j].x, y[e][j].y);
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int g = 0; g < NB; g++) { if (g & 1) S.template step<1>(y[g]); else S.template step<0>(y[g]); }
+                    if (a.stream_start && F < 0) {                // frames before the stream are exactly +0 (the FFT of zeros may hold -0):
+                        asm volatile("" ::: "memory");            // the state they leave is that of a fresh stream (a real branch, once per launch)
+                        S.reset();
+                    }
+                    if (F >= f0 && ((F + NB - 1) & 31) == 31) {   // 32 real frames collected (f0 is a multiple of 64)
+                        const uint64_t n = a.n_done + (uint64_t)(F + NB - 1);   // absolute index of the newest bit
+#pragma unroll
+                        for (int j = 0; j < 2; j++) {
+                            uint32_t word = S.word(j);
+                            if (SL == AMPS_SLICER_PRODUCT && a.stream_start && F + NB - 1 == 31) word |= 7u;   // no partner yet: g = 1
+                            if (ch[j] < a.n_channels) ((uint32_t *)(a.gring + (uint64_t)ch[j] * a.ring_words))[(n >> 5) & mask32] = word;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
         }
     }
 }
@@ -608,6 +1030,13 @@ struct ChannelizerState {
     size_t stage_samples = 0;
     StageFence stage_fence;
 };
+
+inline bool chz_legacy_kernels()   // AMPS_RECC_CHZ=legacy: the 4-wave kernels also for P = 8 (A/B measurements)
+{
+    static int v = -1;
+    if (v < 0) { const char *e = std::getenv("AMPS_RECC_CHZ"); v = (e && e[0] == 'l') ? 1 : 0; }
+    return v == 1;
+}
 
 inline double bessel_i0(double x)
 {
@@ -732,7 +1161,17 @@ inline int channelizer_run(ChannelizerState &z, const float2 *iq, size_t nsamp, 
         a.gring = gring; a.ring_words = ring_words; a.n_done = n_done;
         a.stream_start = z.frames_done == 0 ? 1u : 0u;
         const uint32_t nwg = (nframes + fpw - 1) / fpw;
-        if (fused && slicer == AMPS_SLICER_PRODUCT) {
+        const bool k12 = z.P == 8 && !chz_legacy_kernels();        // the 12-wave pipeline (one workgroup per CU)
+        if (k12) {
+            fpw = std::max<uint32_t>(64u, (nframes + z.target_wgs / 2 - 1) / (z.target_wgs / 2));
+            fpw = (fpw + 63) / 64 * 64;
+            a.frames_per_wg = fpw;
+            const dim3 g12((nframes + fpw - 1) / fpw), b12(768);
+            if (!fused) hipLaunchKernelGGL((chz12_kernel<8, CHZ12_IQ>), g12, b12, 0, s, a);
+            else if (slicer == AMPS_SLICER_PRODUCT) hipLaunchKernelGGL((chz12_kernel<8, AMPS_SLICER_PRODUCT>), g12, b12, 0, s, a);
+            else if (slicer == AMPS_SLICER_SINE) hipLaunchKernelGGL((chz12_kernel<8, AMPS_SLICER_SINE>), g12, b12, 0, s, a);
+            else hipLaunchKernelGGL((chz12_kernel<8, AMPS_SLICER_ATAN_BOXCAR>), g12, b12, 0, s, a);
+        } else if (fused && slicer == AMPS_SLICER_PRODUCT) {
             if (z.P == 8) hipLaunchKernelGGL((chz_fused_kernel<8, AMPS_SLICER_PRODUCT>), dim3(nwg), dim3(256), 0, s, a);
             else hipLaunchKernelGGL((chz_fused_kernel<16, AMPS_SLICER_PRODUCT>), dim3(nwg), dim3(256), 0, s, a);
         } else if (fused && slicer == AMPS_SLICER_SINE) {

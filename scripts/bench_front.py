@@ -1,7 +1,8 @@
 """Microbench of the IQ seam's streaming kernel: ms per 832 x 2^18 push for each slicer spec (HIP events)."""
 import sys
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gr_amps_amd import capi
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
