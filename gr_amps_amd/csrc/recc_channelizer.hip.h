@@ -231,15 +231,22 @@ __device__ __forceinline__ void chz_fold_batch(cf2 (&line)[4][P], const cf2 (&co
 
 // pass 2, radix 16, p = 4, one frame per wave, in place.  lane i: k = i & 3, u[r] = A[i + 64 r] e^{-2 pi i r k / 64},
 // X = DFT16(u), A[16 (i - k) + k + 4 r] = X[r].  tab[r][k] holds the twiddles (LDS, 512 B).
-__device__ __forceinline__ void chz_p2(cf2 *A, const cf2 *tab, int lane)
+template <bool REGS>
+__device__ __forceinline__ void chz_p2_t(cf2 *A, const cf2 *tab, const cf2 (&twr)[15], int lane)
 {
     const int k = lane & 3;
     cf2 u[16];
     const cf2 *src = A + cpad(lane);                            // cpad(lane + 64 r) = cpad(lane) + 68 r
 #pragma unroll
     for (int r = 0; r < 16; r++) u[r] = src[68 * r];
-    {
-        // The 15 twiddles are loop invariant; hoisted out of the batch loop they would pin 30 VGPRs the kernel does
+    if constexpr (REGS) {
+        // 12-wave kernel: the FFT waves have the registers for the 15 twiddles W_64^{r k} (loop invariant).  From the LDS
+        // table the compiler reads them one pair at a time between the multiplies -- eight exposed LDS latencies per pass
+        // (measured with s_memtime: pass 2 took 2950 cycles per frame against 1780 for pass 3, which has its twiddles in registers)
+#pragma unroll
+        for (int r = 1; r < 16; r++) u[r] = cmul(u[r], twr[r - 1]);
+    } else {
+        // The 15 twiddles are loop invariant; hoisted out of the batch loop they would pin 30 VGPRs the 4-wave kernel does
         // not have.  The empty asm hides the invariance of the index (laundering the POINTER instead turns the reads
         // into flat loads); re-reading 120 B of LDS per batch is free.
         int kk = k;
@@ -270,6 +277,12 @@ __device__ __forceinline__ void chz_p2(cf2 *A, const cf2 *tab, int lane)
 #pragma unroll
         for (int d = 0; d < 4; d++) dst[4 * (c + 4 * d) + d] = X[d];   // r = c + 4 d, (r >> 2) = d
     }
+}
+
+__device__ __forceinline__ void chz_p2(cf2 *A, const cf2 *tab, int lane)
+{
+    const cf2 none[15] = {};
+    chz_p2_t<false>(A, tab, none, lane);
 }
 
 // pass 3, radix 4, p = 64: u[r] = B[t + 256 r] e^{-2 pi i r k / 256}, k = t & 63; C[4 (t - k) + k + 64 r] = X[r]
@@ -621,11 +634,7 @@ __device__ __forceinline__ void chz_fold_p1_ring(const cf2 (&ring)[4][P + 4], co
     cf2 o[4];
     dft4(x[0], x[1], x[2], x[3], o);                            // radix 4, p = 1: no twiddles
     cf2 *d = A + cpad(4 * t);
-#if CHZ_EXP == 7 || CHZ_EXP == 8
-    if (o[0].x == 1.2345f) d[0] = o[0] + o[1] + o[2] + o[3];      // timing experiment: keep the arithmetic, drop the LDS stores
-#else
     d[0] = o[0]; d[1] = o[1]; d[2] = o[2]; d[3] = o[3];
-#endif
 }
 // Two frames at a time: eight independent accumulator chains (2 frames x 4 branches), two taps per asm block.  Measured
 // (scripts/ubench_pk2.hip): a lone wave on a SIMD issues v_pk_fma_f32 with three distinct register-pair sources every 7.1
@@ -687,11 +696,7 @@ __device__ __forceinline__ void chz_fold2_ring(const cf2 (&ring)[4][P + 4], cons
         cf2 o[4];
         dft4(acc[f][0], acc[f][1], acc[f][2], acc[f][3], o);     // radix 4, p = 1: no twiddles
         cf2 *d = bufA + (FA + f) * CHZ_FB + cpad(4 * t);
-#if CHZ_EXP == 7 || CHZ_EXP == 8
-        if (o[0].x == 1.2345f) d[0] = o[0] + o[1] + o[2] + o[3];  // timing experiment: keep the arithmetic, drop the LDS stores
-#else
         d[0] = o[0]; d[1] = o[1]; d[2] = o[2]; d[3] = o[3];
-#endif
     }
 }
 template <int P, int BASE>
@@ -757,12 +762,6 @@ __device__ __forceinline__ void chz_ring_wait(cf2 (&ring)[4][P + 4])
 // leave while they wait for LDS, and both roles fit 168 VGPRs: three waves per SIMD.  FFT-1024 = 4 x 16 x 16 needs one
 // LDS round trip less than 4 x 16 x 4 x 4.  The unfused form is the same kernel with a different epilogue (MODE_IQ: the
 // bins go to the channel-major block as 64-byte runs), so fused and unfused forms stay bit-identical by construction.
-#ifndef CHZ_PRIO
-#define CHZ_PRIO 0
-#endif
-#ifndef CHZ_EXP
-#define CHZ_EXP 0            // timing experiments (pieces compiled out; results are wrong): never set in a shipped build
-#endif
 constexpr int CHZ_NB = 8;                                        // frames per batch
 constexpr int CHZ12_IQ = -1;                                     // MODE: write the channel-major block; >= 0: AMPS_SLICER_* fused behind the FFT
 
@@ -898,13 +897,9 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
                 const int64_t F = fs + (int64_t)NB * sidx + CHZ_BATCH * half;
                 cf2 *dst = bufA[sidx & 1] + CHZ_BATCH * half * CHZ_FB;
                 chz_ring_wait<P, BASE>(ring);
-#if CHZ_EXP != 3
                 chz_fold_half_ring<P, BASE>(ring, coef, dst, t);
-#endif
-#if CHZ_EXP != 6 && CHZ_EXP != 8
                 if (in.batch_in_block(F + NB)) chz_load_half_ring<P, BASE, P + 4, true>(ring, in, F + NB, t);
                 else chz_load_half_ring<P, BASE, P + 4, false>(ring, in, F + NB, t);   // generic: zero beyond the data
-#endif
             }
             __syncthreads();
         };
@@ -924,12 +919,9 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
         // ------------------------------------------------------------------ FFT role
         const int u = tid - 256;                                  // 0..511: owns bins u and u + 512
         const int wf = wave - 4;                                  // frame of the batch this wave transforms
-#if CHZ_PRIO
-        __builtin_amdgcn_s_setprio(CHZ_PRIO);                     // the FFT waves are the critical path of a time step
-#endif
-        cf2 tw34[15];
+        cf2 tw2[15], tw34[15];                                    // twiddles of the two radix-16 passes: W_64^{r (lane & 3)}, W_1024^{r lane}
 #pragma unroll
-        for (int r = 1; r < 16; r++) tw34[r - 1] = chz_twiddle(r * lane, 1024);
+        for (int r = 1; r < 16; r++) { tw2[r - 1] = chz_twiddle(r * (lane & 3), 64); tw34[r - 1] = chz_twiddle(r * lane, 1024); }
         ChzSlice2<SL> S;
         S.reset();
         const uint64_t mask32 = 2ull * a.ring_words - 1;
@@ -941,12 +933,8 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
             cf2 *A = bufA[(s - 1) & 1];
             if (s >= 1) {
                 cf2 *Af = A + wf * CHZ_FB;
-#if CHZ_EXP != 2 && CHZ_EXP != 4 && CHZ_EXP < 6
-                chz_p2(Af, tab, lane);
-#endif
-#if CHZ_EXP != 2 && CHZ_EXP != 5 && CHZ_EXP < 6
+                chz_p2_t<true>(Af, tab, tw2, lane);
                 chz_p34(Af, tw34, lane);
-#endif
             }
             __syncthreads();
             if (s >= 1) {
