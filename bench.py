@@ -2,16 +2,27 @@
 """bench.py -- AMPS RECC receive path on MI355X: Manchester symbols demodulated AND decoded per second.
 
 A "step" is one pass of the hot path over one resident batch of synthetic IQ:
-    amps_recc_push_iq / amps_recc_push_wideband (device pointer) + amps_recc_drain (records to host).
-Inputs are in HBM before the timed region starts.  N>1: one process per GPU (torchrun), each rank
-owns its own band of channels (independent 30 kHz channels are the data-parallel axis; no data-path
-collective), value = symbols processed by all ranks / max-over-ranks time  -> "scaling": "weak".
+    amps_recc_push_wideband / amps_recc_push_iq (device pointer) + amps_recc_drain (records to host).
+Inputs are in HBM before the timed region starts.
 
-Prints ONE JSON line (rank 0).  See DESIGN.md section 6 for the definitions of roofline/cpu_baseline.
+N > 1: one process per GPU.  `python bench.py --gpus N` with no WORLD_SIZE in the environment starts the N ranks itself
+(re-exec under torch.distributed.run on 127.0.0.1); under an external torchrun it uses the ranks it is given.
+  --dist bands (default)      every rank owns its own 832-channel band (independent 30 kHz channels / whole bands are the
+                              data-parallel axis): no data-path collective, weak scaling, value = all ranks' symbols / max time
+  --dist broadcast            ONE band: rank 0 owns the step's wideband block and RCCL broadcasts it (flat ncclBroadcast) to
+                              every rank inside the timed region; rank r decodes channel group r of the band
+  --dist scatter_allgather    the same distribution as scatter (B/N per peer) + all-gather (every xGMI
+                              link carries B/N per phase instead of B)
+  In the two one-band modes the filter bank does not shard (every rank runs the whole fold + FFT):
+  value = the band's symbols / max time, "scaling": "strong".
+
+Prints ONE JSON line (rank 0).  See DESIGN.md section 6 for the definitions of roofline / roofline_compute / cpu_baseline.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,26 +33,77 @@ sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_SYMBOL_DIRECT = 80.0   # 8 B/sample x 10 samples/symbol, IQ read once
 HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec (6290 GB/s measured copy ceiling)
+FP32_PEAK_TFLOPS = 157.3             # MI355X_MICROARCH.md: peak FP32 vector rate (packed)
+SLICERS = {"atan": "A", "product": "B", "sine": "C"}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="wideband832", choices=["wideband832", "direct832", "direct1"],
                     help="wideband832 = BASELINE configs[3] (headline): full band through the channelizer; direct832/direct1 = configs[1] style")
     ap.add_argument("--secondary", default="direct832", choices=["none", "direct832", "direct1", "wideband832"],
                     help="a second workload reported under 'secondary' (N=1 only)")
+    ap.add_argument("--slicer", default="sine", choices=list(SLICERS),
+                    help="numeric spec of the slicer (include/amps_recc_numerics.h): atan = spec A (discriminator + boxcar, the library default), "
+                         "sine = spec C (the same without the arctangent), product = spec B.  The other specs' kernel times are reported under 'other_slicer_specs'")
+    ap.add_argument("--dist", default="bands", choices=["bands", "broadcast", "scatter_allgather"])
     ap.add_argument("--samples", type=int, default=0, help="per-channel samples per step (0 = workload default)")
     ap.add_argument("--taps", type=int, default=8, choices=[8, 16], help="wideband832: prototype taps per polyphase branch")
     ap.add_argument("--prewarm-ms", type=float, default=400.0, help="untimed clock-settling run of the same step before the warmup steps")
     ap.add_argument("--no-pipeline", action="store_true", help="drain synchronously after every push instead of one step behind")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-specs", action="store_true", help="skip the short runs of the other slicer specs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
+# ----------------------------------------------------------------------------------------------------- ranks
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_command(n, argv):
+    """the torchrun command line `python bench.py --gpus n ...` re-executes itself under (one rank per GPU, 127.0.0.1)"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n,
+            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "bench.py")] + list(argv)
+
+
+def ensure_world(a, argv):
+    """`--gpus N` without a launcher: start the N ranks ourselves and relay their exit code."""
+    if a.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    sys.stdout.flush()
+    raise SystemExit(subprocess.call(spawn_command(a.gpus, argv), env=env))
+
+
+def plumbing_only(a):
+    """AMPS_BENCH_CPU_PLUMBING=1: the rank plumbing of this file on a box without GPUs (gloo): rendezvous, barrier, max-over-
+    ranks reduction and the rank-0 JSON line -- what tests/test_cpu_bench.py checks for `--gpus 2`."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"plumbing_only": True, "n_gpus": world, "max_over_ranks": float(t.item()), "dist": a.dist}), flush=True)
+
+
+# ----------------------------------------------------------------------------------------------------- inputs
 def make_batch(torch, dev, C, N, sps, seed):
     """C channels x N samples of config-1 style IQ (CPFSK seizure bursts in AWGN) resident on `dev`.
     A base set of distinct channels is synthesised on the CPU and tiled across the band."""
@@ -64,7 +126,7 @@ def make_batch(torch, dev, C, N, sps, seed):
 def make_wideband_batch(torch, dev, nsamp, first_bin, n_channels, every, seed):
     """One wideband block (fs = 30.72 Msps, 1024 x 30 kHz) on `dev`: one random seizure burst in every
     `every`-th active channel at a random offset, AWGN at 30 dB SNR in a channel's 60 kHz.  Built on the GPU
-    (torch is plumbing here): phase = cumsum(f_dev(t)) + 2 pi f_c t.  Returns (complex64 [nsamp], #bursts)."""
+    (torch is plumbing here): phase = cumsum(f_dev(t)) + 2 pi f_c t.  Returns (complex64 [nsamp], {channel: MIN})."""
     from gr_amps_amd import synth, synth_wideband as sw
     rng = np.random.default_rng(seed)
     fs = sw.FS_WIDE
@@ -75,20 +137,21 @@ def make_wideband_batch(torch, dev, nsamp, first_bin, n_channels, every, seed):
     x = torch.randn(nsamp, 2, device=dev, generator=g, dtype=torch.float32) * float(sigma)
     x = torch.view_as_complex(x)
     blen = 3456 * sps_w
-    nb = 0
+    planted = {}
     for c in range(0, n_channels, every):
         k = (first_bin + c) % 1024
-        _, _, _, _, words = synth.random_message(rng)
+        _, min10, _, _, words = synth.random_message(rng)
         sym = synth.manchester(synth.burst_bits(words, dcc=int(rng.integers(0, 4)), rng=rng)).astype(np.float32) * 2 - 1
         off = int(rng.integers(1000, nsamp - blen - 1000))
         f = torch.from_numpy(sym).to(dev).repeat_interleave(sps_w) * (2 * np.pi * 8e3 / fs)
         fc = 2 * np.pi * sw.bin_freq(k) / fs
         ph = torch.cumsum(f.double() + fc, 0) + float(rng.uniform(0, 2 * np.pi)) + fc * off
         x[off:off + blen] += torch.polar(torch.ones_like(ph, dtype=torch.float32), ph.remainder(2 * np.pi).float())
-        nb += 1
-    return x.contiguous(), nb
+        planted[c] = min10
+    return x.contiguous(), planted
 
 
+# ----------------------------------------------------------------------------------------------------- CPU baseline
 def cpu_baseline(iq_base, sps, budget_s):
     """Reference CPU chain (oracle restatement: quadrature demod -> M&M clock recovery -> slicer ->
     recc trigger search/capture -> Manchester -> BCH -> parse), single thread, on a bounded sample of
@@ -135,8 +198,24 @@ def cpu_baseline(iq_base, sps, budget_s):
     }
 
 
-def profile_entry(key):
-    """the PMC-derived entry of this workload in profiles/rNN/traffic.json (newest round), or None"""
+# ----------------------------------------------------------------------------------------------------- flop / byte models
+def chz_flops_per_frame(taps, slicer, n_channels):
+    """Algorithmic flops of the filter-bank kernel per frame (512 new wideband samples), as the kernel computes them:
+    fold 1024 branches x taps x (complex x real = 2 FMA); FFT-1024 = 4 x 16 x 16: 10240 complex adds, 2816 general complex
+    multiplies (twiddles between the passes + inside the radix-16 butterflies); slicer per active bin."""
+    fold = 1024 * taps * 2 * 2
+    fft = 10240 * 2 + 2816 * 6
+    per_bin = {"atan": 8 + 27 + 2, "sine": 3 + 2, "product": 3}[slicer]     # conj-product (+ arctangent) + boxcar adds
+    return fold + fft + per_bin * n_channels
+
+
+def front_flops_per_sample(slicer, sps):
+    return {"atan": 8 + 27, "sine": 3, "product": 3}[slicer] + (0 if slicer == "product" else (sps - 1))
+
+
+def profile_traffic(key):
+    """HBM bytes per launch of this workload's dominant kernel from the newest committed PMC profile (profiles/rNN/traffic.json,
+    separate rocprofv3 --pmc passes) -- a profile figure, reported beside the in-run numbers, never as one of them."""
     pdir = os.path.join(ROOT, "profiles")
     if not os.path.isdir(pdir):
         return None
@@ -146,78 +225,104 @@ def profile_entry(key):
             t = json.load(open(tj))
             for e in (t if isinstance(t, list) else [t]):
                 if e.get("key") == key:
+                    e = dict(e)
+                    e["source"] = "profiles/%s/traffic.json" % tag
                     return e
     return None
 
 
-def traffic_from_profiles(key):
-    """HBM bytes per launch from the PMC passes of the same command (profiles/rNN/traffic.json)."""
-    pdir = os.path.join(ROOT, "profiles")
-    if not os.path.isdir(pdir):
-        return None
-    for tag in sorted(os.listdir(pdir), reverse=True):
-        tj = os.path.join(pdir, tag, "traffic.json")
-        if os.path.exists(tj):
-            t = json.load(open(tj))
-            for e in (t if isinstance(t, list) else [t]):
-                if e.get("key") == key or (key == "direct832" and e.get("algorithmic_bytes_per_launch") == 832 * 262144 * 8 and "key" not in e):
-                    return e["hbm_bytes_per_launch"]
-    return None
-
-
-def run_workload(name, a, torch, dev, dist, rank, world, local):
-    """Build the resident batch, warm up, time exactly a.steps steps (barrier + synchronize on both sides,
-    max over ranks) and return the result fields for this workload."""
+# ----------------------------------------------------------------------------------------------------- one workload
+def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, warmup, light=False):
+    """Build the resident batch, warm up, time exactly `steps` steps (barrier + synchronize on both sides,
+    max over ranks) and return the result fields for this workload.  light = kernel time only (other slicer specs)."""
     from gr_amps_amd import capi
     wide = name == "wideband832"
+    one_band = wide and dist is not None and a.dist != "bands"
+    planted = None
     if wide:
         # config 3: the whole 832-channel band from one 30.72 Msps stream through the polyphase channelizer
         sps, C, first_bin = 3, 832, 96
         NW = a.samples or (1 << 27)                       # wideband samples per step (1 GiB, 4.4 s of signal)
         N = NW // 512                                     # samples per channel after the channelizer
-        batch, expected = make_wideband_batch(torch, dev, NW, first_bin, C, 2, seed=rank + 1)
+        if one_band:                                      # rank r decodes channel group r of rank 0's band
+            C = 832 // world
+            first_bin = 96 + rank * C
+            batch, planted = make_wideband_batch(torch, dev, NW, 96, 832, 2, seed=1)     # the same block everywhere (only rank 0's is used)
+            planted = {c - rank * C: m for c, m in planted.items() if rank * C <= c < (rank + 1) * C}
+            recv = [torch.empty_like(batch), torch.empty_like(batch)]
+        else:
+            batch, planted = make_wideband_batch(torch, dev, NW, first_bin, C, 2, seed=rank + 1)
+        expected = len(planted)
         iq_base = None
         r = capi.Recc(n_channels=C, sps=sps, max_samples=N + 8, max_bursts=max(4096, 2 * expected), device=local, time_kernels=True,
+                      slicer=slicer, sync_torch=False,
                       wideband={"channels": 1024, "decim": 512, "taps_per_branch": a.taps, "first_channel": first_bin})
+        step_no = [0]
+        busy = [None, None]                               # per receive buffer: event behind the kernels that last read it
 
         def push():
-            r.push_wideband(batch)
-
-        def step():
-            push()
-            return r.drain(copy=False)
+            if one_band:
+                # the step's block travels rank 0 -> everybody over xGMI inside the timed region; two receive buffers, so the
+                # collective of step i overlaps the kernels of step i - 1 and only waits for those of step i - 2
+                slot = step_no[0] & 1
+                buf = recv[slot]
+                step_no[0] += 1
+                if busy[slot] is not None:
+                    torch.cuda.current_stream().wait_event(busy[slot])
+                if a.dist == "broadcast":
+                    if rank == 0:
+                        buf.copy_(batch, non_blocking=True)
+                    dist.broadcast(torch.view_as_real(buf), src=0)
+                else:
+                    flat = torch.view_as_real(buf).view(-1)
+                    chunk = flat.numel() // world
+                    mine = flat[rank * chunk:(rank + 1) * chunk]
+                    src = list(torch.view_as_real(batch).view(-1).split(chunk)) if rank == 0 else None
+                    dist.scatter(mine, scatter_list=src, src=0)
+                    dist.all_gather_into_tensor(flat, mine)
+                r.wait_torch()                            # the handle's stream waits for the collective (no host sync)
+                r.push_wideband(buf)
+                busy[slot] = r.record_torch_event()
+            else:
+                r.push_wideband(batch)
     else:
         sps = 10
         C, N = (1, a.samples or (1 << 26)) if name == "direct1" else (832, a.samples or (1 << 18))
         NW = 0
         batch, iq_base, expected = make_batch(torch, dev, C, N, sps, seed=rank + 1)
-        r = capi.Recc(n_channels=C, sps=sps, max_samples=N, max_bursts=max(4096, 2 * expected), device=local, time_kernels=True)
+        r = capi.Recc(n_channels=C, sps=sps, max_samples=N, max_bursts=max(4096, 2 * expected), device=local, time_kernels=True,
+                      slicer=slicer, sync_torch=False)
 
         def push():
             r.push_iq(batch)
+    torch.cuda.synchronize()                               # the batch is complete before the library's stream reads it
 
-        def step():
-            push()
-            return r.drain(copy=False)
+    def step():
+        push()
+        return r.drain(copy=False)
 
     # the metric is SUSTAINED throughput: the GPU's clocks take a few hundred ms of load to settle (kernel time falls
     # ~7 % over the first dozen launches), so the same step runs untimed for --prewarm-ms before the W warmup steps
     tp = time.perf_counter()
-    while (time.perf_counter() - tp) * 1e3 < a.prewarm_ms:
+    while (time.perf_counter() - tp) * 1e3 < (100.0 if light else a.prewarm_ms):
         step()
     recs = None
     r.timing(reset=True)
-    for _ in range(a.warmup):           # the per-kernel breakdown comes from these (all launches bracketed by HIP events)
+    for _ in range(warmup):             # the per-kernel breakdown comes from these (all launches bracketed by HIP events)
         recs = step()
     tm_all = r.timing()
-    n_all = max(a.warmup, 1)
+    n_all = max(warmup, 1)
     # in the timed region only the dominant kernel is bracketed: ten event records per step cost ~3 % of the step
     r.set_timing("dominant")
-    if recs is not None:   # sanity: the decode path really ran -- the planted bursts came back valid
+    checked = None
+    if recs is not None:   # sanity: the decode path really ran -- the planted bursts came back with the transmitted MIN
         if wide:           # a burst cut by the edge of the repeated block may be lost; nearly all must decode
-            assert len(recs) >= 0.97 * expected, (len(recs), expected)
+            ok = sum(1 for g in recs if planted.get(int(g["channel"])) == g["min"].decode() and g["valid"][0])
+            assert ok >= 0.97 * expected, (ok, len(recs), expected)
+            checked = {"planted": expected, "decoded_with_transmitted_MIN": ok}
         else:
             assert len(recs) == expected and recs["valid"].all(), (len(recs), expected)
+            checked = {"planted": expected, "decoded_valid": int(len(recs))}
     r.timing(reset=True)
 
     def barrier():
@@ -229,13 +334,13 @@ def run_workload(name, a, torch, dev, dist, rank, world, local):
     t0 = time.perf_counter()
     nrec = 0
     if a.no_pipeline:
-        for _ in range(a.steps):
+        for _ in range(steps):
             nrec += len(step())
     else:
         # streaming form of the same K steps: the records of step i are collected (split drain) while step i+1 runs, so the
         # GPU does not idle for the ~60 us of host work between steps; every step's records are still drained inside the
         # timed region
-        for i in range(a.steps):
+        for i in range(steps):
             push()
             if i:
                 nrec += len(r.drain_end(copy=False))
@@ -253,45 +358,65 @@ def run_workload(name, a, torch, dev, dist, rank, world, local):
     del batch
     torch.cuda.empty_cache()
     syms_per_step_rank = C * (NW / 1536.0) if wide else C * N / sps
-    value = syms_per_step_rank * a.steps * world / el
-    if wide:   # dominant kernel = the channelizer; algorithmic bytes = the wideband block read once (14.77 B/symbol)
+    value = syms_per_step_rank * steps * world / el      # one-band modes: the ranks' channel groups add up to the band
+    if wide:   # dominant kernel = the channelizer; algorithmic bytes = the wideband block read once (14.77 B/symbol at 832 channels)
         kms = tm["ms_channelizer"] / max(1, tm["launches_channelizer"])
         alg_bytes = 8.0 * NW
-        kname = "chz_fused_kernel<%d>" % a.taps
-        note = ("filter bank + FFT-1024 + FM discriminator + boxcar + slicer in one kernel (~35 flop per input byte): VALU-issue "
-                "bound (PMC: VALU active ~85 % of busy cycles), not HBM bound; the HBM fraction is what the metric asks for.  Only slicer bits (1/64 of the input) reach HBM; "
-                "the bit-domain correlator (ms_front) and the decode kernels follow")
+        kname = "chz12_kernel<%d, slicer %s>" % (a.taps, SLICERS[slicer]) if a.taps == 8 else "chz_fused_kernel<16>"
+        flops = chz_flops_per_frame(a.taps, slicer, C) * (NW / 512.0)
+        note = ("filter bank (fold + FFT-1024 = 4 x 16 x 16) + slicer spec %s in one kernel, %.1f flop per input byte: bound by VALU issue "
+                "and LDS exchange, not by HBM (both rooflines are reported; the HBM fraction is what the metric asks for).  Only slicer bits "
+                "(1/64 of the input) reach HBM; the bit-domain correlator (ms_front) and the decode kernels follow" % (SLICERS[slicer], flops / alg_bytes))
     else:
         kms = tm["ms_front"] / max(1, tm["launches_front"])
         alg_bytes = ALG_BYTES_PER_SYMBOL_DIRECT * syms_per_step_rank
-        kname = "recc_front_kernel<10,1>"
-        note = "streaming kernel; VALU issue and HBM are both within ~25 % of their limits"
+        kname = "recc_front_kernel<10,1, slicer %s>" % SLICERS[slicer]
+        flops = front_flops_per_sample(slicer, sps) * float(C) * N
+        note = "streaming kernel: HBM-bound by design (%.1f flop per input byte)" % (flops / alg_bytes)
+    if light:
+        return {"kernel": kname, "kernel_ms": round(kms, 4), "value": round(value / 1e6, 3), "checked": checked}, iq_base
     ach = alg_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+    tfl = flops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
     drain_note = "" if a.no_pipeline else " (split drain: collected while the next step runs)"
+    prof = profile_traffic(name + ":" + slicer)
+    par = ("%s: rank 0's block by RCCL %s every step, rank r decodes channels [%d r, %d (r+1)); the filter bank runs on every rank"
+           % (a.dist, "broadcast" if a.dist == "broadcast" else "scatter + all-gather", C, C)) if one_band else \
+          "bands sharded x%d (one 832-channel band per GPU), no data-path collective" % world
     res = {
-        "value": round(value / 1e6, 3), "ms_per_step": round(el / a.steps * 1e3, 4),
+        "value": round(value / 1e6, 3), "ms_per_step": round(el / steps * 1e3, 4),
         "config": {"workload": ("wideband832 (BASELINE configs[3]): one fc32 stream @30.72 Msps, %d samples per step per GPU -> 1024-branch "
-                                "polyphase channelizer -> 832 RECC channels @60 ksps -> fused demod+sync+BCH(63,51) decode, records drained "
-                                "every step%s" % (NW, drain_note)) if wide else
+                                "polyphase channelizer -> 832 RECC channels @60 ksps -> fused slicer (numeric spec %s) + sync + BCH(63,51) decode, "
+                                "records drained every step%s" % (NW, SLICERS[slicer], drain_note)) if wide else
                                ("%s (BASELINE configs[1] batched): %d RECC channels x %d fc32 IQ samples @200 ksps per step per GPU, channel-major, "
-                                "fused demod+sync+BCH(63,51) decode, records drained every step%s" % (name, C, N, drain_note)),
-                   "channels_per_gpu": C, "samples_per_channel": N, "samples_per_symbol": sps,
+                                "fused slicer (numeric spec %s) + sync + BCH(63,51) decode, records drained every step%s"
+                                % (name, C, N, SLICERS[slicer], drain_note)),
+                   "channels_per_gpu": C, "samples_per_channel": N, "samples_per_symbol": sps, "slicer_spec": SLICERS[slicer],
                    "algorithmic_bytes_per_symbol": round(alg_bytes / syms_per_step_rank, 2),
                    "realtime_channels_per_gpu": round(value / world / 20e3, 1),
-                   "bursts_decoded_per_step_per_gpu": nrec // max(1, a.steps), "parallelism": "channels sharded x%d, no data-path collective" % world},
+                   "bursts_decoded_per_step_per_gpu": nrec // max(1, steps), "checked": checked, "parallelism": par},
         "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic_from_profiles(name),
-                     "valu_issue_frac_pmc": (profile_entry(name) or {}).get("valu_issue_frac"),
-                     "kernel": kname, "kernel_ms": round(kms, 4), "note": note,
+                     "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "traffic_note": "HBM counters need separate rocprofv3 --pmc passes; the committed profile of this command is under 'traffic_profile'",
+                     "traffic_profile": prof,
+                     "kernel": kname, "kernel_ms": round(kms, 4), "launches_timed": int(tm["launches_channelizer"] if wide else tm["launches_front"]),
+                     "algorithmic_bytes_per_launch": alg_bytes, "note": note,
                      "frac_of_measured_copy_ceiling_6290": round(ach / 6290.0, 4),
                      "other_kernels_ms_per_step": {k: round(tm_all[k] / n_all, 4) for k in ("ms_front", "ms_resolve", "ms_decode", "ms_carry", "ms_channelizer")},
                      "other_kernels_from": "the %d warmup steps (all kernels bracketed); kernel_ms is from the timed steps" % n_all},
+        "roofline_compute": {"bound": "valu_fp32", "flop_per_launch": flops, "achieved": round(tfl, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(tfl / FP32_PEAK_TFLOPS, 4), "flop_per_byte": round(flops / alg_bytes, 2),
+                             "kernel": kname, "kernel_ms": round(kms, 4),
+                             "note": "algorithmic flops of the same kernel (model in bench.py: chz_flops_per_frame / front_flops_per_sample) over the same in-run HIP-event duration"},
     }
     return res, iq_base
 
 
-def main():
-    a = parse()
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    a = parse(argv)
+    ensure_world(a, argv)
+    if os.environ.get("AMPS_BENCH_CPU_PLUMBING") == "1":
+        return plumbing_only(a)
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -301,6 +426,8 @@ def main():
         raise SystemExit("--gpus must equal WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the RECC path has no CPU fallback")
+    if local >= torch.cuda.device_count():
+        raise SystemExit("rank %d: only %d GPU(s) visible on this node" % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -309,18 +436,32 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if a.dist != "bands" and a.workload != "wideband832":
+        raise SystemExit("--dist %s distributes a wideband block: use --workload wideband832" % a.dist)
 
-    res, iq_base = run_workload(a.workload, a, torch, dev, dist, rank, world, local)
+    res, iq_base = run_workload(a.workload, a, torch, dev, dist, rank, world, local, a.slicer, a.steps, a.warmup)
     out = {
         "metric": "AMPS RECC Manchester symbols demodulated+decoded per second (real-time channels = value/0.02); achieved HBM GB/s vs peak",
         "value": res["value"], "unit": "Msym/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": res["ms_per_step"], "higher_is_better": True,
+        "scaling": "weak" if (a.dist == "bands" or world == 1) else "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": res["config"], "roofline": res["roofline"], "prewarm_ms": a.prewarm_ms,
+        "config": res["config"], "roofline": res["roofline"], "roofline_compute": res["roofline_compute"], "prewarm_ms": a.prewarm_ms,
+        "dist": a.dist,
     }
+    if world == 1 and not a.no_other_specs:
+        # the same workload under the other slicer specs (short runs: kernel time + the decode check), so that the cost of
+        # the arctangent of spec A -- the library's default numeric spec -- is on the record beside the headline
+        other = {}
+        for sp in SLICERS:
+            if sp != a.slicer:
+                o, _ = run_workload(a.workload, a, torch, dev, None, 0, 1, local, sp, 20, 3, light=True)
+                other[SLICERS[sp]] = o
+        out["other_slicer_specs"] = other
     if world == 1 and a.secondary != "none" and a.secondary != a.workload:
-        sec, sec_base = run_workload(a.secondary, a, torch, dev, None, 0, 1, local)
-        out["secondary"] = {"value": sec["value"], "unit": "Msym/s", "ms_per_step": sec["ms_per_step"], "config": sec["config"], "roofline": sec["roofline"]}
+        sec, sec_base = run_workload(a.secondary, a, torch, dev, None, 0, 1, local, a.slicer, a.steps, a.warmup)
+        out["secondary"] = {"value": sec["value"], "unit": "Msym/s", "ms_per_step": sec["ms_per_step"], "config": sec["config"],
+                            "roofline": sec["roofline"], "roofline_compute": sec["roofline_compute"]}
         if iq_base is None:
             iq_base = sec_base
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -332,7 +473,12 @@ def main():
                                                "would also run -- 'with_channel_filter' times the chain including it")
     if dist is not None:
         dist.destroy_process_group()
-    if rank == 0:          # the JSON line is the last thing written (RCCL prints its banner before this)
+    if rank == 0:          # the JSON line is the last thing written: RCCL's banner sits in the C library's stdout buffer until
+        import ctypes      # exit when stdout is a pipe, so that buffer is flushed first
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         sys.stderr.flush()
         print(json.dumps(out), flush=True)
 

@@ -85,6 +85,7 @@ EXPORTS = (
     "amps_bch_encode_words", "amps_bch_decode_words",
     "amps_recc_set_xlate", "amps_recc_push_raw", "amps_recc_debug_xlate", "amps_recc_set_timing",
     "amps_recc_drain_begin", "amps_recc_drain_end", "amps_recc_set_origin",
+    "amps_recc_wait_event", "amps_recc_record_event",
 )
 
 _lib = None
@@ -121,6 +122,8 @@ def load():
     L.amps_recc_push_iq.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int]
     L.amps_recc_push_wideband.argtypes = [vp, vp, C.c_size_t, C.c_int]
     L.amps_recc_drain.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.amps_recc_wait_event.argtypes = [vp, vp]
+    L.amps_recc_record_event.argtypes = [vp, vp]
     L.amps_recc_drain_begin.argtypes = [vp]
     L.amps_recc_drain_end.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.amps_recc_debug_demod.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, vp, vp]
@@ -146,12 +149,18 @@ def _hostptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def _as_ptr(x):
-    """numpy array -> (pointer, MEM_HOST, keepalive); torch CUDA tensor -> (pointer, MEM_DEVICE, keepalive)"""
+def _as_ptr(x, sync_torch=True):
+    """numpy array -> (pointer, MEM_HOST, keepalive); torch CUDA tensor -> (pointer, MEM_DEVICE, keepalive).
+    The library launches on its own non-blocking stream, which is not ordered against torch's: a device tensor is pushed
+    only after the torch stream that produced it has drained (a pageable H2D copy or a generator kernel may still be in
+    flight when .to() / randn() return).  Callers that order the streams themselves (Recc.wait_torch) pass sync_torch=False."""
     if isinstance(x, np.ndarray):
         return _hostptr(x), MEM_HOST, x
     if hasattr(x, "data_ptr"):
         if x.is_cuda:
+            if sync_torch:
+                import torch
+                torch.cuda.current_stream(x.device).synchronize()
             return C.c_void_p(x.data_ptr()), MEM_DEVICE, x
         a = x.numpy()
         return _hostptr(a), MEM_HOST, a
@@ -162,8 +171,10 @@ class Recc:
     """One handle = `n_channels` independent RECC receivers on one MI355X."""
 
     def __init__(self, n_channels=1, sps=10, max_samples=0, max_bursts=1024, device=-1, time_kernels=False,
-                 stream=None, wideband=None, majority=False, unfused_wideband=False, sync_tolerance=0, slicer="atan"):
+                 stream=None, wideband=None, majority=False, unfused_wideband=False, sync_tolerance=0, slicer="atan",
+                 sync_torch=True):
         L = load()
+        self.sync_torch = sync_torch
         cfg = Cfg()
         cfg.struct_size = C.sizeof(Cfg)
         cfg.n_channels = n_channels
@@ -216,7 +227,7 @@ class Recc:
         syms2 = syms.reshape(self.n_channels, -1)
         ld = syms2.shape[1]
         n = ld if n is None else n
-        ptr, mem, keep = _as_ptr(syms2)
+        ptr, mem, keep = _as_ptr(syms2, self.sync_torch)
         out = np.zeros((self.max_bursts, CAPTURE), np.uint8)
         ch = np.zeros(self.max_bursts, np.uint32)
         nout = C.c_size_t(0)
@@ -232,7 +243,7 @@ class Recc:
         out = np.zeros(nb, BURST_DTYPE)
         if nb == 0:
             return out
-        ptr, mem, keep = _as_ptr(bursts)
+        ptr, mem, keep = _as_ptr(bursts, self.sync_torch)
         chp = None
         if channels is not None:
             channels = np.ascontiguousarray(channels, np.uint32)
@@ -251,7 +262,7 @@ class Recc:
         else:
             ld = iq.shape[1]
         nsamp = ld if nsamp is None else nsamp
-        ptr, mem, keep = _as_ptr(iq)
+        ptr, mem, keep = _as_ptr(iq, self.sync_torch)
         rc = load().amps_recc_push_iq(self._h, ptr, ld, nsamp, mem)
         if rc:
             raise AmpsError(rc, "amps_recc_push_iq")
@@ -270,7 +281,7 @@ class Recc:
             iq = np.ascontiguousarray(iq, np.complex64).reshape(self.n_channels, -1)
         ld = iq.shape[1]
         nsamp = ld if nsamp is None else nsamp
-        ptr, mem, keep = _as_ptr(iq)
+        ptr, mem, keep = _as_ptr(iq, self.sync_torch)
         rc = load().amps_recc_push_raw(self._h, ptr, ld, nsamp, mem)
         if rc:
             raise AmpsError(rc, "amps_recc_push_raw")
@@ -293,10 +304,32 @@ class Recc:
         if isinstance(iq, np.ndarray):
             iq = np.ascontiguousarray(iq, np.complex64).reshape(-1)
         n = iq.shape[0]
-        ptr, mem, keep = _as_ptr(iq)
+        ptr, mem, keep = _as_ptr(iq, self.sync_torch)
         rc = load().amps_recc_push_wideband(self._h, ptr, n, mem)
         if rc:
             raise AmpsError(rc, "amps_recc_push_wideband")
+
+    def wait_torch(self, stream=None):
+        """Order later pushes behind everything enqueued so far on a torch CUDA stream (default: the current one), without
+        blocking the host: an event is recorded on that stream and the handle's stream waits for it."""
+        import torch
+        ev = torch.cuda.Event()
+        ev.record(stream or torch.cuda.current_stream())
+        rc = load().amps_recc_wait_event(self._h, C.c_void_p(ev.cuda_event))
+        if rc:
+            raise AmpsError(rc, "amps_recc_wait_event")
+        self._keep_ev = ev
+
+    def record_torch_event(self):
+        """The converse: a torch event recorded behind everything this handle has enqueued so far; a torch stream that
+        waits for it (stream.wait_event) may then overwrite a buffer the handle's kernels read."""
+        import torch
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())          # creates the underlying hipEvent_t
+        rc = load().amps_recc_record_event(self._h, C.c_void_p(ev.cuda_event))
+        if rc:
+            raise AmpsError(rc, "amps_recc_record_event")
+        return ev
 
     def bch_encode(self, msg_bits):
         """uint8 [n][k] message bits -> uint8 [n][k+12] code words (k = 28: FOCC/FVC, k = 36: RECC)."""

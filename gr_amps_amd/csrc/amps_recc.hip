@@ -796,6 +796,22 @@ int amps_recc_debug_xlate(amps_recc_t *h, const float *iq, size_t ld, size_t nsa
     return 0;
 }
 
+int amps_recc_wait_event(amps_recc_t *h, void *hip_event)
+{
+    if (!h || !hip_event) return -EINVAL;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamWaitEvent(h->stream, (hipEvent_t)hip_event, 0));
+    return 0;
+}
+
+int amps_recc_record_event(amps_recc_t *h, void *hip_event)
+{
+    if (!h || !hip_event) return -EINVAL;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipEventRecord((hipEvent_t)hip_event, h->stream));
+    return 0;
+}
+
 int amps_recc_drain_begin(amps_recc_t *h)
 {
     if (!h) return -EINVAL;

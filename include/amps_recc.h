@@ -224,6 +224,16 @@ int amps_recc_push_raw(amps_recc_t *h, const float *iq, size_t ld, size_t nsamp,
 int amps_recc_debug_xlate(amps_recc_t *h, const float *iq, size_t ld, size_t nsamp, int mem,
                           float *out, size_t out_ld, size_t *nout);
 
+/* Stream ordering for DEVICE buffers.  A handle created with cfg.stream = NULL launches on its own non-blocking stream,
+ * which is not ordered against any other stream: a device buffer must have been completely written before it is pushed.
+ * Either synchronise the producing stream first, or record an event behind the producer and hand it over here: work
+ * enqueued by LATER calls on this handle waits for it (hipStreamWaitEvent; nothing blocks on the host).  `hip_event` is
+ * a hipEvent_t. */
+int amps_recc_wait_event(amps_recc_t *h, void *hip_event);
+/* the converse: records `hip_event` (a hipEvent_t of the caller) behind everything enqueued on the handle so far, so that
+ * another stream can wait for the handle's kernels before it overwrites a buffer they read */
+int amps_recc_record_event(amps_recc_t *h, void *hip_event);
+
 /* Synchronise the handle's stream and copy out the decoded bursts accumulated since the last
  * drain, sorted by (channel, position).  -ENOSPC if the device list overflowed max_bursts
  * (the first max_bursts records are still returned). */
