@@ -229,6 +229,18 @@ __device__ __forceinline__ void chz_fold_batch(cf2 (&line)[4][P], const cf2 (&co
         for (int q = 0; q < P; q++) line[jb][q] = ext[jb][q + 2];
 }
 
+// LDS layouts of the 12-wave kernel's frame buffers (cf2 elements).  cpad's one pad element per 16 makes the 8-byte READS of 32
+// consecutive lanes span 33 elements, so lane 31 lands on lane 0's banks (one extra LDS cycle on every read of passes 2 and 3
+// and of the slicer: 17 % of the LDS cycles were bank conflicts); here every access of the pipeline is conflict free:
+//   chz_pos1: pass-1 output, element 4 t + k1 at t + 260 k1 -- the fold's stores are stride 1 across lanes, and pass 2's gather
+//             (the compiler pairs its reads into ds_read2_b64: 16-lane groups, 16 bank pairs) hits (i >> 2) + 4 (i & 3) mod 16:
+//             with cpad, or with 264 k1, every such read was a 2-way conflict (PMC: exactly 8 conflict cycles per ds_read2);
+//   chz_pos2: pass-2 and pass-3 output, n + 4 (n >> 6): no padding inside 64 consecutive elements (reads i + 64 r of
+//             consecutive lanes are consecutive), and the stride-64 write-back of pass 2 advances 8 banks per four lanes.
+__host__ __device__ constexpr int chz_pos1(int t, int k1) { return t + 260 * k1; }
+__host__ __device__ constexpr int chz_pos2(int n) { return n + 4 * (n >> 6); }
+static_assert(chz_pos1(255, 3) < CHZ_FB && chz_pos2(1023) < CHZ_FB, "frame buffer too small for the 12-wave layouts");
+
 // pass 2, radix 16, p = 4, one frame per wave, in place.  lane i: k = i & 3, u[r] = A[i + 64 r] e^{-2 pi i r k / 64},
 // X = DFT16(u), A[16 (i - k) + k + 4 r] = X[r].  tab[r][k] holds the twiddles (LDS, 512 B).
 template <bool REGS>
@@ -236,9 +248,17 @@ __device__ __forceinline__ void chz_p2_t(cf2 *A, const cf2 *tab, const cf2 (&twr
 {
     const int k = lane & 3;
     cf2 u[16];
-    const cf2 *src = A + cpad(lane);                            // cpad(lane + 64 r) = cpad(lane) + 68 r
+    if constexpr (REGS) {
+        // 12-wave kernel: pass 1 left element 4 t + k1 at chz_pos1(t, k1): lane i wants 4 t + k1 = i + 64 r, i.e.
+        // t = (i >> 2) + 16 r, k1 = i & 3
+        const cf2 *src = A + chz_pos1(lane >> 2, k);
 #pragma unroll
-    for (int r = 0; r < 16; r++) u[r] = src[68 * r];
+        for (int r = 0; r < 16; r++) u[r] = src[16 * r];
+    } else {
+        const cf2 *src = A + cpad(lane);                        // cpad(lane + 64 r) = cpad(lane) + 68 r
+#pragma unroll
+        for (int r = 0; r < 16; r++) u[r] = src[68 * r];
+    }
     if constexpr (REGS) {
         // 12-wave kernel: the FFT waves have the registers for the 15 twiddles W_64^{r k} (loop invariant).  From the LDS
         // table the compiler reads them one pair at a time between the multiplies -- eight exposed LDS latencies per pass
@@ -269,6 +289,16 @@ __device__ __forceinline__ void chz_p2_t(cf2 *A, const cf2 *tab, const cf2 (&twr
     v[3][2] = cmul_s(v[3][2], (cf2){ -R2, -R2 });               // W16^6
     v[3][3] = cmul_s(v[3][3], (cf2){ -C1, S1 });                // W16^9
     // all reads of this wave precede its writes in program order; nobody else touches this frame during pass 2
+    if constexpr (REGS) {
+        cf2 *dst = A + 17 * (lane - k) + k;                     // chz_pos2(16 (i-k) + k + 4 r) = 17 (i-k) + k + 4 r   (k + 4 r < 64)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            cf2 X[4];
+            dft4(v[0][c], v[1][c], v[2][c], v[3][c], X);
+#pragma unroll
+            for (int d = 0; d < 4; d++) dst[4 * (c + 4 * d)] = X[d];
+        }
+    } else {
     cf2 *dst = A + 17 * (lane - k) + k;                         // cpad(16 (i-k) + k + 4 r) = 17 (i-k) + k + 4 r + (r >> 2)
 #pragma unroll
     for (int c = 0; c < 4; c++) {
@@ -276,6 +306,7 @@ __device__ __forceinline__ void chz_p2_t(cf2 *A, const cf2 *tab, const cf2 (&twr
         dft4(v[0][c], v[1][c], v[2][c], v[3][c], X);
 #pragma unroll
         for (int d = 0; d < 4; d++) dst[4 * (c + 4 * d) + d] = X[d];   // r = c + 4 d, (r >> 2) = d
+    }
     }
 }
 
@@ -614,28 +645,7 @@ __global__ __launch_bounds__(256, P <= 8 ? 2 : 1) void chz_fused_kernel(ChzArgs 
 // the fold the two oldest slots are dead and receive the loads of the half-step after next, and BASE advances by two: no
 // register ever moves (the 4-wave kernels shift 32 register pairs per four frames), and a load has two half-steps to land.
 // The half-step loop is unrolled over the ring's period of (P + 4) / 2 rotations.
-template <int P, int PAR, int SA, int SB, int BASE>
-__device__ __forceinline__ void chz_fold_p1_ring(const cf2 (&ring)[4][P + 4], const cf2 (&coef)[4][P / 2], cf2 *A, int t)
-{
-    constexpr int R = P + 4;
-    constexpr int SW = 2 * ((PAR + 1) & 1);
-    cf2 x[4];
-#pragma unroll
-    for (int jb = 0; jb < 4; jb++) {
-        const int sh = jb < 2 ? SA : SB;
-        cf2 s = { 0.f, 0.f };
-#pragma unroll
-        for (int q = 0; q < P; q += 2) {                            // taps q, q+1 share one coefficient pair
-            s = fma_lo(ring[jb][(BASE + sh + q) % R], coef[jb ^ SW][q / 2], s);
-            s = fma_hi(ring[jb][(BASE + sh + q + 1) % R], coef[jb ^ SW][q / 2], s);
-        }
-        x[jb] = s;
-    }
-    cf2 o[4];
-    dft4(x[0], x[1], x[2], x[3], o);                            // radix 4, p = 1: no twiddles
-    cf2 *d = A + cpad(4 * t);
-    d[0] = o[0]; d[1] = o[1]; d[2] = o[2]; d[3] = o[3];
-}
+//
 // Two frames at a time: eight independent accumulator chains (2 frames x 4 branches), two taps per asm block.  Measured
 // (scripts/ubench_pk2.hip): a lone wave on a SIMD issues v_pk_fma_f32 with three distinct register-pair sources every 7.1
 // cycles with 4 chains and one-instruction asm statements (the compiler puts an s_nop behind every group of dependent asm
@@ -695,8 +705,8 @@ __device__ __forceinline__ void chz_fold2_ring(const cf2 (&ring)[4][P + 4], cons
     for (int f = 0; f < 2; f++) {
         cf2 o[4];
         dft4(acc[f][0], acc[f][1], acc[f][2], acc[f][3], o);     // radix 4, p = 1: no twiddles
-        cf2 *d = bufA + (FA + f) * CHZ_FB + cpad(4 * t);
-        d[0] = o[0]; d[1] = o[1]; d[2] = o[2]; d[3] = o[3];
+        cf2 *d = bufA + (FA + f) * CHZ_FB + t;
+        d[chz_pos1(0, 0)] = o[0]; d[chz_pos1(0, 1)] = o[1]; d[chz_pos1(0, 2)] = o[2]; d[chz_pos1(0, 3)] = o[3];
     }
 }
 template <int P, int BASE>
@@ -770,7 +780,7 @@ constexpr int CHZ12_IQ = -1;                                     // MODE: write 
 __device__ __forceinline__ void chz_p34(cf2 *A, const cf2 (&tw)[15], int lane)
 {
     cf2 u[16];
-    cf2 *src = A + cpad(lane);                                  // cpad(lane + 64 r) = cpad(lane) + 68 r
+    cf2 *src = A + lane;                                        // chz_pos2(lane + 64 r) = lane + 68 r
 #pragma unroll
     for (int r = 0; r < 16; r++) u[r] = src[68 * r];
 #pragma unroll
@@ -924,6 +934,8 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
         for (int r = 1; r < 16; r++) { tw2[r - 1] = chz_twiddle(r * (lane & 3), 64); tw34[r - 1] = chz_twiddle(r * lane, 1024); }
         ChzSlice2<SL> S;
         S.reset();
+        uint32_t hold[2][4] = {};                                 // finished ring words of the two bins waiting for their 16-byte store
+        int nheld = 0;
         const uint64_t mask32 = 2ull * a.ring_words - 1;
         uint32_t ch[2];
 #pragma unroll
@@ -941,7 +953,7 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
                 const int64_t F = fs + (int64_t)NB * (s - 1);     // first frame of the batch (multiple of 8)
                 cf2 y[NB][2];
 #pragma unroll
-                for (int g = 0; g < NB; g++) { y[g][0] = A[g * CHZ_FB + cpad(u)]; y[g][1] = A[g * CHZ_FB + cpad(u + 512)]; }
+                for (int g = 0; g < NB; g++) { y[g][0] = A[g * CHZ_FB + chz_pos2(u)]; y[g][1] = A[g * CHZ_FB + chz_pos2(u + 512)]; }
                 if constexpr (IQ) {
                     // eight frames of a bin leave as one 64-byte run of the channel-major block
                     const int ng = (int)(f1 - F < (int64_t)NB ? f1 - F : (int64_t)NB);
@@ -968,12 +980,30 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
                         S.reset();
                     }
                     if (F >= f0 && ((F + NB - 1) & 31) == 31) {   // 32 real frames collected (f0 is a multiple of 64)
-                        const uint64_t n = a.n_done + (uint64_t)(F + NB - 1);   // absolute index of the newest bit
+                        // A channel's words leave as ONE 16-byte store per 128 frames (aligned group of four ring dwords): single
+                        // dwords scattered over the channels' ring rows are counted -- and written -- as 32-byte sectors, 8x the 27 MB
+                        // of slicer bits per GiB of input (round 1: 215 MB of 1.36 GB traffic).  Ranges start and end on 64-frame
+                        // boundaries, so a run that is not a whole group is exactly two words.
+                        const uint64_t w = (a.n_done + (uint64_t)(F + NB - 1)) >> 5;   // absolute ring dword of the finished word
+                        const bool last = F + NB >= f1;
 #pragma unroll
                         for (int j = 0; j < 2; j++) {
                             uint32_t word = S.word(j);
                             if (SL == AMPS_SLICER_PRODUCT && a.stream_start && F + NB - 1 == 31) word |= 7u;   // no partner yet: g = 1
-                            if (ch[j] < a.n_channels) ((uint32_t *)(a.gring + (uint64_t)ch[j] * a.ring_words))[(n >> 5) & mask32] = word;
+                            hold[j][0] = hold[j][1]; hold[j][1] = hold[j][2]; hold[j][2] = hold[j][3]; hold[j][3] = word;
+                        }
+                        nheld++;
+                        if ((w & 3) == 3 || last) {
+#pragma unroll
+                            for (int j = 0; j < 2; j++) {
+                                if (ch[j] < a.n_channels) {
+                                    uint32_t *row = (uint32_t *)(a.gring + (uint64_t)ch[j] * a.ring_words);
+                                    if (nheld == 4 && (w & 3) == 3) *(uint4 *)(row + ((w - 3) & mask32)) = make_uint4(hold[j][0], hold[j][1], hold[j][2], hold[j][3]);
+                                    else if (nheld == 2) *(uint2 *)(row + ((w - 1) & mask32)) = make_uint2(hold[j][2], hold[j][3]);
+                                    else for (int k = 0; k < nheld; k++) row[(w - (uint64_t)(nheld - 1 - k)) & mask32] = hold[j][4 - nheld + k];   // not reached: ranges are multiples of 64 frames
+                                }
+                            }
+                            nheld = 0;
                         }
                     }
                 }

@@ -1,20 +1,22 @@
 #!/bin/bash
 # rocprofv3 evidence for one round: kernel-trace stats of the default bench command and separate PMC passes.
-# usage (GPU box, repo root): scripts/profile_round.sh <tag>      -> gpurun_out/prof_<tag>/
-TAG=${1:-r01}
+# usage (GPU box, repo root): scripts/profile_round.sh <tag> [slicer]      -> gpurun_out/prof_<tag>/
+TAG=${1:-r02}; SL=${2:-sine}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline"          # wideband832 + secondary direct832
+BENCH="python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-other-specs --slicer $SL"          # wideband832 + secondary direct832
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
-SHORT="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+SHORT="python $R/bench.py --steps 4 --warmup 2 --prewarm-ms 50 --no-cpu-baseline --no-other-specs --slicer $SL"
 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmc1 -o pmc -- $SHORT > $OUT/pmc1.log 2>&1
 rocprofv3 --output-format csv --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU GRBM_GUI_ACTIVE -d $OUT/pmc2 -o pmc -- $SHORT > $OUT/pmc2.log 2>&1
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $SHORT > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $SHORT > $OUT/pmc_write.log 2>&1
 find $OUT -type f ! -name "*.csv" ! -name "*.log" -delete
-for k in chz_fused "recc_front_kernel<10" "recc_bits_kernel"; do echo "== $k"; python $R/scripts/pmc_summary.py $OUT "$k"; done | tee $OUT/pmc_kernels.txt
+for k in "chz12_kernel" "recc_front_kernel<10" "recc_bits_kernel"; do echo "== $k"; python $R/scripts/pmc_summary.py $OUT "$k"; done | tee $OUT/pmc_kernels.txt
+python $R/scripts/make_traffic_json.py $OUT $SL > $OUT/traffic.json
+cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
 # keep the summaries, drop the raw per-dispatch tables (tens of MB: gpurun merges at most 64 MiB back)
 find $OUT -name "*counter_collection.csv" -delete
 find $OUT -name "*kernel_trace.csv" -delete
