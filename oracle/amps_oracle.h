@@ -8,10 +8,30 @@
  * PARITY STATUS (see DESIGN.md "Oracle"):  the reference cannot be built in this image -- every
  * source file on the path includes GNU Radio / IT++ / Boost headers that are absent, and writing
  * stand-ins for them is not allowed -- and the reference's own test-suite is empty
- * (lib/qa_amps.cc:9-15).  The integer stages are pinned ONLY to (a) the constants embedded in the
- * reference sources and (b) the known-answer values SURVEY.md section 8a records from the
- * reference's compiled code; the float stages (GNU Radio blocks) and the BCH boolean (IT++) are
- * "parity unpinned".
+ * (lib/qa_amps.cc:9-15): NO reference-produced vector exists, so parity stays "partial".  What pins
+ * each row instead (tests/test_cpu_oracle.py, tests/test_cpu_oracle_pins.py, tests/test_gpu_pins.py):
+ *   R1 trigger, R3 Manchester, R6/R7 word + MIN parse, TX word builders
+ *        the constants embedded in the reference sources + the known-answer values SURVEY.md 8a
+ *        recorded from the reference's compiled code (tests/golden/survey_kats.json)
+ *   R2 recc_impl::work
+ *        the recorded stream behaviours Q1-Q4 (3/3/3/2 bursts for chunk 1000/4096/333/8191; wrap loss)
+ *   R4 itpp::BCH(63,2,true)
+ *        an INDEPENDENT brute-force decoder (tests/bchref.py: integer polynomial arithmetic, coset
+ *        leaders) on all 4096 syndromes and all 39711 weight-3 patterns, including the documented
+ *        IT++ rule "#roots == deg Lambda" (S1 = 0, S3 a cube: 21 syndromes are "corrected" at weight
+ *        3); the encoder against polynomial division.  The IT++ VERSION is unpinned
+ *        (CMakeLists.txt:89 names none): a release whose decode() differs from the published 4.x
+ *        algorithm on uncorrectable words would differ from this restatement there
+ *   G1 firdes.low_pass, G2 fast_atan2f, G3's MMSE table
+ *        the blocks' published invariants (tap count / DC gain / symmetry / -6 dB cutoff / Blackman
+ *        stop band; exact special cases and the 255-interval interpolation error bound; unit rows,
+ *        mirror symmetry, DC gain, band-limited interpolation error) -- NOT GNU Radio's literal
+ *        tables: the MMSE rows are the closed-form least-squares solution of the same objective,
+ *        equal to the shipped table only to its print precision
+ *   still unpinned: R5/R8 control flow of bursts_message beyond the cited lines read side by side;
+ *        G3's loop arithmetic (clock_recovery_mm_ff) and G1's rotator renormalisation period, which
+ *        only a GNU Radio build could confirm; word-level equality with the restated chain is
+ *        self-consistency, not reference parity.
  */
 #ifndef AMPS_ORACLE_H
 #define AMPS_ORACLE_H
