@@ -85,7 +85,7 @@ EXPORTS = (
     "amps_bch_encode_words", "amps_bch_decode_words",
     "amps_recc_set_xlate", "amps_recc_push_raw", "amps_recc_debug_xlate", "amps_recc_set_timing",
     "amps_recc_drain_begin", "amps_recc_drain_end", "amps_recc_set_origin",
-    "amps_recc_wait_event", "amps_recc_record_event",
+    "amps_recc_wait_event", "amps_recc_record_event", "amps_recc_refchain_symbols", "amps_recc_refchain_tables",
 )
 
 _lib = None
@@ -122,6 +122,8 @@ def load():
     L.amps_recc_push_iq.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int]
     L.amps_recc_push_wideband.argtypes = [vp, vp, C.c_size_t, C.c_int]
     L.amps_recc_drain.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.amps_recc_refchain_symbols.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, vp, C.c_size_t, vp]
+    L.amps_recc_refchain_tables.argtypes = [vp, vp, vp]
     L.amps_recc_wait_event.argtypes = [vp, vp]
     L.amps_recc_record_event.argtypes = [vp, vp]
     L.amps_recc_drain_begin.argtypes = [vp]
@@ -308,6 +310,28 @@ class Recc:
         rc = load().amps_recc_push_wideband(self._h, ptr, n, mem)
         if rc:
             raise AmpsError(rc, "amps_recc_push_wideband")
+
+    def refchain_symbols(self, iq):
+        """The flow graph's own sub-chain (quadrature_demod_cf -> clock_recovery_mm_ff -> binary_slicer_fb) on the device:
+        complex64 [C][n] at 200 ksps -> list of uint8 symbol arrays, one per channel (continues across calls)."""
+        if isinstance(iq, np.ndarray):
+            iq = np.ascontiguousarray(iq, np.complex64).reshape(self.n_channels, -1)
+        n = iq.shape[1]
+        ptr, mem, keep = _as_ptr(iq, self.sync_torch)
+        cap = n // 9 + 16
+        out = np.zeros((self.n_channels, cap), np.uint8)
+        ns = np.zeros(self.n_channels, np.uint32)
+        rc = load().amps_recc_refchain_symbols(self._h, ptr, n, n, mem, _hostptr(out), cap, _hostptr(ns))
+        if rc:
+            raise AmpsError(rc, "amps_recc_refchain_symbols")
+        return [out[c, :ns[c]].copy() for c in range(self.n_channels)]
+
+    def refchain_tables(self):
+        a, m = np.zeros(258, np.float32), np.zeros((129, 8), np.float32)
+        rc = load().amps_recc_refchain_tables(self._h, _hostptr(a), _hostptr(m))
+        if rc:
+            raise AmpsError(rc, "amps_recc_refchain_tables")
+        return a, m
 
     def wait_torch(self, stream=None):
         """Order later pushes behind everything enqueued so far on a torch CUDA stream (default: the current one), without

@@ -19,6 +19,7 @@
 #include "recc_channelizer.hip.h"
 #include "recc_xlate.hip.h"
 #include "recc_bits.hip.h"
+#include "recc_refchain.hip.h"
 
 static_assert(sizeof(amps_recc_burst_t) == AMPS_RECC_BURST_BYTES, "record layout is part of the ABI");
 static_assert(sizeof(amps_recc_burst_t) % 8 == 0, "records are copied as dwords");
@@ -85,6 +86,9 @@ struct amps_recc {
 
     // ---- translate seam (recctest.grc channel filter) ----
     XlateState xl;
+
+    // ---- reference-timing seam (G2 -> G3 -> G4 as the flow graph wires them; created on first use) ----
+    RefState ref;
 
     // ---- symbol seam ----
     uint8_t *symbuf = nullptr;
@@ -221,6 +225,8 @@ int reset_state(amps_recc *h)
     int rc = channelizer_reset(h->chz, s);
     if (rc) return rc;
     rc = xlate_reset(h->xl, s);
+    if (rc) return rc;
+    rc = ref_reset(h->ref, s);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(s));
     return 0;
@@ -525,6 +531,7 @@ void amps_recc_destroy(amps_recc_t *h)
     if (h->hdr_host) (void)hipHostFree(h->hdr_host);
     channelizer_destroy(h->chz);
     xlate_destroy(h->xl);
+    ref_destroy(h->ref);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -793,6 +800,44 @@ int amps_recc_debug_xlate(amps_recc_t *h, const float *iq, size_t ld, size_t nsa
         HIP_TRY(hipMemcpy2DAsync(out, out_ld * sizeof(float2), f, fld * sizeof(float2), (size_t)n * sizeof(float2), h->C,
                                  hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int amps_recc_refchain_symbols(amps_recc_t *h, const float *iq, size_t ld, size_t nsamp, int mem,
+                               uint8_t *symbols_out, size_t sym_ld, uint32_t *nsym_out)
+{
+    if (!h || !symbols_out || !nsym_out || (nsamp && (!iq || ld < nsamp))) return -EINVAL;
+    if (!h->cfg.max_samples_per_push) return -ENOSYS;
+    if (h->sps != 10) return -EINVAL;                       // the flow graph's omega = 10 samples per symbol
+    if (nsamp > h->cfg.max_samples_per_push) return -E2BIG;
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    if (!h->ref.ready) { if (int rc = ref_create(h->ref, h->C, h->cfg.max_samples_per_push, s)) return rc; }
+    if (sym_ld < h->ref.sym_cap && sym_ld < nsamp / 9 + 16) return -EINVAL;
+    const float2 *d = (const float2 *)iq;
+    uint64_t dld = ld;
+    if (mem == AMPS_MEM_HOST && nsamp) {
+        if (!h->ref.stage && dev_alloc(&h->ref.stage, (size_t)h->C * h->cfg.max_samples_per_push)) return -ENOMEM;
+        dld = nsamp;
+        HIP_TRY(hipMemcpy2D(h->ref.stage, dld * sizeof(float2), iq, ld * sizeof(float2), nsamp * sizeof(float2), h->C, hipMemcpyHostToDevice));
+        d = h->ref.stage;
+    }
+    if (int rc = ref_run(h->ref, d, dld, (uint32_t)nsamp, s)) return rc;
+    HIP_TRY(hipMemcpyAsync(nsym_out, h->ref.nsym, sizeof(uint32_t) * h->C, hipMemcpyDeviceToHost, s));
+    const size_t w = std::min<size_t>(sym_ld, h->ref.sym_cap);
+    HIP_TRY(hipMemcpy2DAsync(symbols_out, sym_ld, h->ref.syms, h->ref.sym_cap, w, h->C, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+int amps_recc_refchain_tables(amps_recc_t *h, float *atan258, float *mmse1032)
+{
+    if (!h || !atan258 || !mmse1032) return -EINVAL;
+    if (!h->cfg.max_samples_per_push) return -ENOSYS;
+    HIP_TRY(hipSetDevice(h->device));
+    if (!h->ref.ready) { if (int rc = ref_create(h->ref, h->C, h->cfg.max_samples_per_push, h->stream)) return rc; }
+    std::memcpy(atan258, h->ref.atan_host.data(), sizeof(float) * 258);
+    std::memcpy(mmse1032, h->ref.mmse_host.data(), sizeof(float) * 129 * 8);
     return 0;
 }
 

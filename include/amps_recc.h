@@ -224,6 +224,18 @@ int amps_recc_push_raw(amps_recc_t *h, const float *iq, size_t ld, size_t nsamp,
 int amps_recc_debug_xlate(amps_recc_t *h, const float *iq, size_t ld, size_t nsamp, int mem,
                           float *out, size_t out_ld, size_t *nout);
 
+/* Reference-timing seam (checking mode): the flow graph's OWN sub-chain in front of amps_recc, computed on the device as GNU
+ * Radio 3.7 defines it -- analog.quadrature_demod_cf(1) -> digital.clock_recovery_mm_ff(omega 10, gain_omega .25*.175^2*3,
+ * mu 0, gain_mu .05, omega_relative_limit .005) -> digital.binary_slicer_fb (grc/recctest.grc:458, 846-874, 807) -- for
+ * every channel of a channel-major fc32 block at 200 ksps (samples_per_symbol must be 10).  The Mueller & Mueller loop is
+ * a sequential recursion: one lane per channel.  symbols_out is host memory [n_channels][sym_ld] (values 0/1: exactly the
+ * byte stream gr::amps::recc::work is fed), nsym_out[c] the number produced for channel c by this call (<= nsamp/9 + 16);
+ * stream state continues across calls.  Feed the symbols to amps_recc_push_symbols for the reference chain end to end. */
+int amps_recc_refchain_symbols(amps_recc_t *h, const float *iq, size_t ld, size_t nsamp, int mem,
+                               uint8_t *symbols_out, size_t sym_ld, uint32_t *nsym_out);
+/* test tap: the two tables the seam uses (fast_atan2f: 258 floats, MMSE interpolator: 129 x 8 floats) */
+int amps_recc_refchain_tables(amps_recc_t *h, float *atan258, float *mmse1032);
+
 /* Stream ordering for DEVICE buffers.  A handle created with cfg.stream = NULL launches on its own non-blocking stream,
  * which is not ordered against any other stream: a device buffer must have been completely written before it is pushed.
  * Either synchronise the producing stream first, or record an event behind the producer and hand it over here: work

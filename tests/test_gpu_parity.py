@@ -242,32 +242,38 @@ def test_fused_words_equal_reference_cpu_chain(gpu):
     synthetic seizure bursts: 400 ksps @ +160 kHz -> 299-tap channel filter -> 200 ksps; both paths
     consume the same 200 ksps stream.  Burst spacing keeps the reference's chunk quirks (Q2-Q4) away."""
     taps = oracle.firdes_low_pass(3, 400e3, 10e3, 4.5e3)
-    n_ref, n_gpu = 0, 0
+    trig = oracle.trigger()
+    report = []
     for seed in range(4):
         iq400, truth = synth.make_channel_block(2 * 400000, 12, seed=500 + seed, sps=20,
                                                 spacing=(3456 + 74 + 4096 + 600) * 20)
         n = np.arange(iq400.size)
         iq400 = (iq400 * np.exp(2j * np.pi * 160e3 * n / 400e3)).astype(np.complex64)
         y = oracle.freq_xlating_fir(iq400, taps, 160e3, 400e3, 2)
-        ref = oracle.chain_iq200(y, chunk=4096)
+        ref, ref_syms = oracle.chain_iq200(y, chunk=4096, want_symbols=True)
         with capi.Recc(n_channels=1, sps=10, max_samples=len(y), max_bursts=64) as r:
             r.push_iq(y[None, :])
             got = r.drain()
-        assert len(got) == len(truth)
+        assert len(got) == len(truth)                     # the fused path finds every transmitted burst
         by_min = {g["min"]: g for g in got}
         for rr in ref:
             assert rr["min"] in by_min, "reference decoded a burst the fused path missed"
             g = by_min[rr["min"]]
-            nw = 2 + int(g["a_NAWC"]) - 1 if False else None
             # all seven 48-bit words the transmitter defined, raw repeat 0 and corrected bits, bit-exact
             assert np.array_equal(rr["word_raw"], g["word_raw"])
             assert np.array_equal(rr["word_dec"], g["word_dec"])
             assert np.array_equal(rr["valid"], g["valid"]) and np.array_equal(rr["dcc"], g["dcc"])
             for f in ("msg_class", "a_MIN1", "b_MIN2", "esn", "dialed", "min", "b_ORDER", "a_NAWC"):
                 assert rr[f] == g[f], f
-        n_ref += len(ref)
-        n_gpu += len(got)
-    assert n_ref >= 0.5 * n_gpu, (n_ref, n_gpu)   # the M&M chain must have locked on most bursts
+        # every burst the restated chain does NOT deliver is explained: its M&M loop had not acquired symbol timing within the
+        # four dotting bits a precursor has to spare (30 sent, 26 in the exact-match trigger of lib/recc_impl.cc:76,118), so
+        # the 74-symbol trigger never appears in ITS symbol stream -- triggers in the stream == bursts delivered
+        w = np.lib.stride_tricks.sliding_window_view(ref_syms, 74)
+        n_trig = int((w == trig).all(axis=1).sum())
+        assert n_trig == len(ref), (seed, n_trig, len(ref))
+        report.append((seed, len(truth), len(got), len(ref)))
+        assert len(ref) >= 0.7 * len(truth), report       # compared fraction per seed (measured 0.75 - 0.92)
+    print("seed, transmitted, fused, reference chain:", report)
 
 
 def test_full_size_roundtrip_properties(gpu):
