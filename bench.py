@@ -126,7 +126,7 @@ def make_batch(torch, dev, C, N, sps, seed):
 def make_wideband_batch(torch, dev, nsamp, first_bin, n_channels, every, seed):
     """One wideband block (fs = 30.72 Msps, 1024 x 30 kHz) on `dev`: one random seizure burst in every
     `every`-th active channel at a random offset, AWGN at 30 dB SNR in a channel's 60 kHz.  Built on the GPU
-    (torch is plumbing here): phase = cumsum(f_dev(t)) + 2 pi f_c t.  Returns (complex64 [nsamp], {channel: MIN})."""
+    (torch is plumbing here): phase = cumsum(f_dev(t)) + 2 pi f_c t.  Returns (complex64 [nsamp], {channel: (MIN, words36)})."""
     from gr_amps_amd import synth, synth_wideband as sw
     rng = np.random.default_rng(seed)
     fs = sw.FS_WIDE
@@ -147,7 +147,7 @@ def make_wideband_batch(torch, dev, nsamp, first_bin, n_channels, every, seed):
         fc = 2 * np.pi * sw.bin_freq(k) / fs
         ph = torch.cumsum(f.double() + fc, 0) + float(rng.uniform(0, 2 * np.pi)) + fc * off
         x[off:off + blen] += torch.polar(torch.ones_like(ph, dtype=torch.float32), ph.remainder(2 * np.pi).float())
-        planted[c] = min10
+        planted[c] = (min10, words)
     return x.contiguous(), planted
 
 
@@ -317,7 +317,7 @@ def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, w
     checked = None
     if recs is not None:   # sanity: the decode path really ran -- the planted bursts came back with the transmitted MIN
         if wide:           # a burst cut by the edge of the repeated block may be lost; nearly all must decode
-            ok = sum(1 for g in recs if planted.get(int(g["channel"])) == g["min"].decode() and g["valid"][0])
+            ok = sum(1 for g in recs if planted.get(int(g["channel"]), (None,))[0] == g["min"].decode() and g["valid"][0])
             assert ok >= 0.97 * expected, (ok, len(recs), expected)
             checked = {"planted": expected, "decoded_with_transmitted_MIN": ok}
         else:

@@ -1123,7 +1123,8 @@ inline int channelizer_create(ChannelizerState &z, const amps_recc_cfg_t &cfg, h
     if (hipMemcpy(z.taps, h.data(), sizeof(float) * L, hipMemcpyHostToDevice) != hipSuccess) return -EIO;
     if (hipMalloc((void **)&z.carry[0], sizeof(float2) * chz_carry_cap(P)) != hipSuccess) return -ENOMEM;
     if (hipMalloc((void **)&z.carry[1], sizeof(float2) * chz_carry_cap(P)) != hipSuccess) return -ENOMEM;
-    if (hipMalloc((void **)&z.out, sizeof(float2) * (size_t)z.C * z.ld) != hipSuccess) return -ENOMEM;
+    // z.out (the channel-major block, C x ld x 8 B: 1.7 GB for a full band at 2^18 frames per push) is allocated by the first
+    // unfused / debug run: the fused form never touches it
     {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -1158,6 +1159,7 @@ inline int channelizer_run(ChannelizerState &z, const float2 *iq, size_t nsamp, 
         if (hipMemcpy(z.stage, iq, sizeof(float2) * nsamp, hipMemcpyHostToDevice) != hipSuccess) return -EIO;
         d = z.stage;
     }
+    if (!fused && !z.out && hipMalloc((void **)&z.out, sizeof(float2) * (size_t)z.C * z.ld) != hipSuccess) return -ENOMEM;
     const uint32_t hist = chz_hist(z.P);
     const uint32_t leftover = z.carry_len - hist;
     const uint64_t avail = (uint64_t)leftover + nsamp;

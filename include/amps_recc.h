@@ -185,7 +185,8 @@ int  amps_recc_set_origin(amps_recc_t *h, uint64_t first_sample);
 int amps_recc_push_symbols(amps_recc_t *h, const uint8_t *syms, size_t ld, int n, int mem,
                            uint8_t *bursts_out, uint32_t *burst_channel, size_t cap, size_t *nout);
 
-/* recc_decode core on a batch of 3374-byte bursts ([nbursts][3374], host or device); out is host. */
+/* recc_decode core on a batch of 3374-byte bursts ([nbursts][3374], host or device per `mem`); out and burst_channel are
+ * always HOST memory. */
 int amps_recc_decode_bursts(amps_recc_t *h, const uint8_t *bursts, size_t nbursts, int mem,
                             const uint32_t *burst_channel /* may be NULL */, amps_recc_burst_t *out);
 
