@@ -20,6 +20,7 @@ FLAG_MAJORITY = 2
 FLAG_UNFUSED_WIDEBAND = 4
 FLAG_SLICER_PRODUCT = 8
 FLAG_SLICER_SINE = 16
+FLAG_KEEP_BURSTS = 32
 
 MSG_CLASSES = ("invalid_word_a", "e_zero", "page_response", "registration", "origination", "bad_nawc", "unknown")
 
@@ -86,6 +87,7 @@ EXPORTS = (
     "amps_recc_set_xlate", "amps_recc_push_raw", "amps_recc_debug_xlate", "amps_recc_set_timing",
     "amps_recc_drain_begin", "amps_recc_drain_end", "amps_recc_set_origin",
     "amps_recc_wait_event", "amps_recc_record_event", "amps_recc_refchain_symbols", "amps_recc_refchain_tables",
+    "amps_recc_drain_bursts",
 )
 
 _lib = None
@@ -126,6 +128,7 @@ def load():
     L.amps_recc_refchain_tables.argtypes = [vp, vp, vp]
     L.amps_recc_wait_event.argtypes = [vp, vp]
     L.amps_recc_record_event.argtypes = [vp, vp]
+    L.amps_recc_drain_bursts.argtypes = [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.amps_recc_drain_begin.argtypes = [vp]
     L.amps_recc_drain_end.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.amps_recc_debug_demod.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, vp, vp]
@@ -174,7 +177,7 @@ class Recc:
 
     def __init__(self, n_channels=1, sps=10, max_samples=0, max_bursts=1024, device=-1, time_kernels=False,
                  stream=None, wideband=None, majority=False, unfused_wideband=False, sync_tolerance=0, slicer="atan",
-                 sync_torch=True):
+                 sync_torch=True, keep_bursts=False):
         L = load()
         self.sync_torch = sync_torch
         cfg = Cfg()
@@ -187,7 +190,8 @@ class Recc:
         cfg.flags = ((FLAG_TIME_KERNELS if time_kernels else 0) | (FLAG_MAJORITY if majority else 0)
                      | (FLAG_UNFUSED_WIDEBAND if unfused_wideband else 0)
                      | (FLAG_SLICER_PRODUCT if slicer in ("product", 1) else 0)
-                     | (FLAG_SLICER_SINE if slicer in ("sine", 2) else 0))
+                     | (FLAG_SLICER_SINE if slicer in ("sine", 2) else 0)
+                     | (FLAG_KEEP_BURSTS if keep_bursts else 0))
         cfg.stream = stream
         cfg.sync_tolerance = sync_tolerance
         if wideband:
@@ -402,6 +406,17 @@ class Recc:
         if rc:
             raise AmpsError(rc, "amps_recc_drain")
         return out[:nout.value].copy() if copy else out[:nout.value]
+
+    def drain_bursts(self, cap=None):
+        """drain() plus the 3374 captured symbol bytes of every record (handle created with keep_bursts=True)"""
+        cap = cap or self.max_bursts
+        out = np.empty(cap, BURST_DTYPE)
+        sym = np.zeros((cap, CAPTURE), np.uint8)
+        nout = C.c_size_t(0)
+        rc = load().amps_recc_drain_bursts(self._h, _hostptr(out), _hostptr(sym), cap, C.byref(nout))
+        if rc:
+            raise AmpsError(rc, "amps_recc_drain_bursts")
+        return out[:nout.value].copy(), sym[:nout.value].copy()
 
     def set_origin(self, first_sample):
         """absolute index of the first sample pushed after create / reset (multiple of 64)"""

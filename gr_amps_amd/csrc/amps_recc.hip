@@ -74,6 +74,7 @@ struct amps_recc {
     uint32_t *hdr_host = nullptr;             // pinned {nrecords, status} per record list
     // two record lists: pushes append to the current one; drain_begin closes it (and switches), drain_end collects it
     amps_recc_burst_t *rec_host_buf[2] = { nullptr, nullptr }, *records_buf[2] = { nullptr, nullptr };
+    uint8_t *bsym_host_buf[2] = { nullptr, nullptr }, *bsym_dev_buf[2] = { nullptr, nullptr };   // AMPS_RECC_FLAG_KEEP_BURSTS: [max_bursts][3374], mapped pinned
     uint32_t *nrecords_buf[2] = { nullptr, nullptr }, *status_buf[2] = { nullptr, nullptr };
     int cur_buf = 0, open_buf = -1;
     hipEvent_t drain_event = nullptr;
@@ -111,6 +112,10 @@ struct amps_recc {
     double ms[T_COUNT] = { 0 };
     uint32_t launches_front = 0, launches_chz = 0;
     uint64_t samples_front = 0;
+
+    // ---- amps_bch_* scratch (grow-only; no allocation per call) ----
+    uint8_t *bch_in = nullptr, *bch_out = nullptr, *bch_val = nullptr, *bch_err = nullptr;
+    size_t bch_in_cap = 0, bch_out_cap = 0, bch_n_cap = 0;
 
     // ---- debug taps (amps_recc_debug_demod) ----
     float *dbg_d = nullptr, *dbg_S = nullptr;
@@ -375,6 +380,7 @@ int run_iq_device(amps_recc *h, const float2 *iq, uint64_t ld, uint32_t nsamp)
         ca.gring = h->gring; ca.ring_mask = h->ring_words - 1; ca.ring_words = h->ring_words;
         ca.records = h->records; ca.nrecords = h->nrecords; ca.rec_cap = h->cfg.max_bursts; ca.status = h->status;
         ca.majority = (h->cfg.flags & AMPS_RECC_FLAG_MAJORITY) ? 1u : 0u;
+        ca.burst_syms = h->bsym_dev_buf[h->cur_buf];
         {
             SpanGuard g(h, T_DECODE);
             uint32_t grid = std::min<uint32_t>(h->cfg.max_bursts, 2048u);
@@ -466,6 +472,10 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
     for (int b = 0; b < 2; b++)
         if (hipHostMalloc((void **)&h->rec_host_buf[b], sizeof(amps_recc_burst_t) * (size_t)cfg->max_bursts, hipHostMallocMapped) != hipSuccess ||
             hipHostGetDevicePointer((void **)&h->records_buf[b], h->rec_host_buf[b], 0) != hipSuccess) rc |= -ENOMEM;
+    if (cfg->flags & AMPS_RECC_FLAG_KEEP_BURSTS)
+        for (int b = 0; b < 2; b++)
+            if (hipHostMalloc((void **)&h->bsym_host_buf[b], (size_t)cfg->max_bursts * AMPS_RECC_CAPTURE_SYMS, hipHostMallocMapped) != hipSuccess ||
+                hipHostGetDevicePointer((void **)&h->bsym_dev_buf[b], h->bsym_host_buf[b], 0) != hipSuccess) rc |= -ENOMEM;
     if (hipHostMalloc((void **)&h->hdr_host, 4 * sizeof(uint32_t)) != hipSuccess) rc |= -ENOMEM;
     if (hipEventCreateWithFlags(&h->drain_event, hipEventDisableTiming) != hipSuccess) rc |= -ENOMEM;
     if (!rc) select_record_list(h, 0);
@@ -524,9 +534,10 @@ void amps_recc_destroy(amps_recc_t *h)
     void *bufs[] = { h->carry[0], h->carry[1], h->gring, h->det, h->detcount, h->next_allowed, h->pending, h->capq,
                      h->capq_count, h->nrecords_buf[0], h->nrecords_buf[1], h->stage_iq, h->symbuf, h->sym_len, h->sym_cur,
                      h->sym_stage, h->bursts_dev, h->burst_chan_dev, h->nbursts_dev, h->dec_out_dev, h->dec_in_dev,
-                     h->dec_chan_dev, h->dbg_d, h->dbg_S };
+                     h->dec_chan_dev, h->dbg_d, h->dbg_S, h->bch_in, h->bch_out, h->bch_val, h->bch_err };
     for (void *p : bufs) if (p) (void)hipFree(p);
     for (int b = 0; b < 2; b++) if (h->rec_host_buf[b]) (void)hipHostFree(h->rec_host_buf[b]);
+    for (int b = 0; b < 2; b++) if (h->bsym_host_buf[b]) (void)hipHostFree(h->bsym_host_buf[b]);
     if (h->drain_event) (void)hipEventDestroy(h->drain_event);
     if (h->hdr_host) (void)hipHostFree(h->hdr_host);
     channelizer_destroy(h->chz);
@@ -709,6 +720,7 @@ int run_bits_device(amps_recc *h, uint32_t P)
     ca.gring = h->gring; ca.ring_mask = h->ring_words - 1; ca.ring_words = h->ring_words;
     ca.records = h->records; ca.nrecords = h->nrecords; ca.rec_cap = h->cfg.max_bursts; ca.status = h->status;
     ca.majority = (h->cfg.flags & AMPS_RECC_FLAG_MAJORITY) ? 1u : 0u;
+    ca.burst_syms = h->bsym_dev_buf[h->cur_buf];
     {
         SpanGuard g(h, T_DECODE);
         hipLaunchKernelGGL(recc_capture_kernel, dim3(std::min<uint32_t>(h->cfg.max_bursts, 2048u)), dim3(64), 0, s, ca);
@@ -872,7 +884,21 @@ int amps_recc_drain_begin(amps_recc_t *h)
     return 0;
 }
 
-int amps_recc_drain_end(amps_recc_t *h, amps_recc_burst_t *out, size_t cap, size_t *nout)
+static int drain_end_impl(amps_recc_t *h, amps_recc_burst_t *out, uint8_t *bursts_out, size_t cap, size_t *nout);
+int amps_recc_drain_end(amps_recc_t *h, amps_recc_burst_t *out, size_t cap, size_t *nout) { return drain_end_impl(h, out, nullptr, cap, nout); }
+
+int amps_recc_drain_bursts(amps_recc_t *h, amps_recc_burst_t *out, uint8_t *bursts_out, size_t cap, size_t *nout)
+{
+    if (!h || !nout || !bursts_out) return -EINVAL;
+    *nout = 0;
+    if (!(h->cfg.flags & AMPS_RECC_FLAG_KEEP_BURSTS)) return -ENOSYS;
+    if (h->open_buf >= 0) return -EBUSY;
+    int rc = amps_recc_drain_begin(h);
+    if (rc) return rc;
+    return drain_end_impl(h, out, bursts_out, cap, nout);
+}
+
+static int drain_end_impl(amps_recc_t *h, amps_recc_burst_t *out, uint8_t *bursts_out, size_t cap, size_t *nout)
 {
     if (!h || !nout) return -EINVAL;
     *nout = 0;
@@ -898,6 +924,9 @@ int amps_recc_drain_end(amps_recc_t *h, amps_recc_burst_t *out, size_t cap, size
         std::sort(keys.begin(), keys.end(), [](const Key &x, const Key &y) { return x.k < y.k; });
         size_t k = std::min<size_t>(n, cap);
         if (out) for (size_t i = 0; i < k; i++) std::memcpy(&out[i], &r[keys[i].i], sizeof(amps_recc_burst_t));
+        if (bursts_out && h->bsym_host_buf[b])
+            for (size_t i = 0; i < k; i++)
+                std::memcpy(bursts_out + i * AMPS_RECC_CAPTURE_SYMS, h->bsym_host_buf[b] + (size_t)keys[i].i * AMPS_RECC_CAPTURE_SYMS, AMPS_RECC_CAPTURE_SYMS);
         *nout = k;
         if (n > cap) rc = -ENOSPC;
     }
@@ -1028,12 +1057,23 @@ int amps_recc_get_timing(amps_recc_t *h, amps_recc_timing_t *t, int reset)
 }
 
 // ---- BCH(63,51) shortened: batch encode / decode on the device
-static int bch_io(amps_recc_t *h, const uint8_t *in, size_t nin, int mem, uint8_t **din)
+// scratch buffers live in the handle and only ever grow: a call costs one launch, its copies and one synchronise
+static int bch_grow(uint8_t **p, size_t *cap, size_t need)
 {
-    *din = nullptr;
-    if (mem == AMPS_MEM_DEVICE) { *din = const_cast<uint8_t *>(in); return 0; }
-    if (hipMalloc((void **)din, nin ? nin : 1) != hipSuccess) return -ENOMEM;
-    if (hipMemcpyAsync(*din, in, nin, hipMemcpyHostToDevice, h->stream) != hipSuccess) { (void)hipFree(*din); return -EIO; }
+    if (need <= *cap) return 0;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; *cap = 0;
+    size_t want = need < 4096 ? 4096 : need + need / 2;
+    if (hipMalloc((void **)p, want) != hipSuccess) return -ENOMEM;
+    *cap = want;
+    return 0;
+}
+static int bch_stage_in(amps_recc_t *h, const uint8_t *in, size_t nin, int mem, const uint8_t **din)
+{
+    if (mem == AMPS_MEM_DEVICE) { *din = in; return 0; }
+    if (int rc = bch_grow(&h->bch_in, &h->bch_in_cap, nin)) return rc;
+    if (hipMemcpyAsync(h->bch_in, in, nin, hipMemcpyHostToDevice, h->stream) != hipSuccess) return -EIO;
+    *din = h->bch_in;
     return 0;
 }
 
@@ -1042,20 +1082,15 @@ int amps_bch_encode_words(amps_recc_t *h, const uint8_t *msg, size_t nwords, int
     if (!h || k < 1 || k > 51 || (nwords && (!msg || !codewords))) return -EINVAL;
     if (nwords == 0) return 0;
     HIP_TRY(hipSetDevice(h->device));
-    uint8_t *din = nullptr, *dout = nullptr;
-    int rc = bch_io(h, msg, nwords * k, mem, &din);
-    if (rc) return rc;
+    const uint8_t *din = nullptr;
+    if (int rc = bch_stage_in(h, msg, nwords * k, mem, &din)) return rc;
     const size_t nout = nwords * (size_t)(k + 12);
-    if (hipMalloc((void **)&dout, nout) != hipSuccess) rc = -ENOMEM;
-    if (!rc) {
-        hipLaunchKernelGGL(bch_encode_words_kernel, dim3((unsigned)std::min<size_t>((nwords + 255) / 256, 4096)), dim3(256), 0, h->stream,
-                           din, (uint32_t)nwords, k, dout);
-        if (hipMemcpyAsync(codewords, dout, nout, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
-            hipStreamSynchronize(h->stream) != hipSuccess) rc = -EIO;
-    }
-    if (mem != AMPS_MEM_DEVICE && din) (void)hipFree(din);
-    if (dout) (void)hipFree(dout);
-    return rc;
+    if (int rc = bch_grow(&h->bch_out, &h->bch_out_cap, nout)) return rc;
+    hipLaunchKernelGGL(bch_encode_words_kernel, dim3((unsigned)std::min<size_t>((nwords + 255) / 256, 4096)), dim3(256), 0, h->stream,
+                       din, (uint32_t)nwords, k, h->bch_out);
+    HIP_TRY(hipMemcpyAsync(codewords, h->bch_out, nout, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
 }
 
 int amps_bch_decode_words(amps_recc_t *h, const uint8_t *codewords, size_t nwords, int k, int mem, uint8_t *msg, uint8_t *valid, uint8_t *nerrors)
@@ -1063,23 +1098,21 @@ int amps_bch_decode_words(amps_recc_t *h, const uint8_t *codewords, size_t nword
     if (!h || k < 1 || k > 51 || (nwords && (!codewords || !msg || !valid))) return -EINVAL;
     if (nwords == 0) return 0;
     HIP_TRY(hipSetDevice(h->device));
-    uint8_t *din = nullptr, *dmsg = nullptr, *dval = nullptr, *derr = nullptr;
-    int rc = bch_io(h, codewords, nwords * (size_t)(k + 12), mem, &din);
-    if (rc) return rc;
-    if (hipMalloc((void **)&dmsg, nwords * k) != hipSuccess || hipMalloc((void **)&dval, nwords) != hipSuccess ||
-        hipMalloc((void **)&derr, nwords) != hipSuccess) rc = -ENOMEM;
-    if (!rc) {
-        hipLaunchKernelGGL(bch_decode_words_kernel, dim3((unsigned)std::min<size_t>((nwords + 255) / 256, 4096)), dim3(256), 0, h->stream,
-                           din, (uint32_t)nwords, k, dmsg, dval, derr);
-        bool bad = hipMemcpyAsync(msg, dmsg, nwords * k, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
-                   hipMemcpyAsync(valid, dval, nwords, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
-                   (nerrors && hipMemcpyAsync(nerrors, derr, nwords, hipMemcpyDeviceToHost, h->stream) != hipSuccess) ||
-                   hipStreamSynchronize(h->stream) != hipSuccess;
-        if (bad) rc = -EIO;
+    const uint8_t *din = nullptr;
+    if (int rc = bch_stage_in(h, codewords, nwords * (size_t)(k + 12), mem, &din)) return rc;
+    if (int rc = bch_grow(&h->bch_out, &h->bch_out_cap, nwords * (size_t)k)) return rc;
+    if (nwords > h->bch_n_cap) {
+        size_t c1 = h->bch_n_cap, c2 = h->bch_n_cap;
+        if (bch_grow(&h->bch_val, &c1, nwords) || bch_grow(&h->bch_err, &c2, nwords)) { h->bch_n_cap = 0; return -ENOMEM; }
+        h->bch_n_cap = std::min(c1, c2);
     }
-    if (mem != AMPS_MEM_DEVICE && din) (void)hipFree(din);
-    for (uint8_t *p : { dmsg, dval, derr }) if (p) (void)hipFree(p);
-    return rc;
+    hipLaunchKernelGGL(bch_decode_words_kernel, dim3((unsigned)std::min<size_t>((nwords + 255) / 256, 4096)), dim3(256), 0, h->stream,
+                       din, (uint32_t)nwords, k, h->bch_out, h->bch_val, h->bch_err);
+    HIP_TRY(hipMemcpyAsync(msg, h->bch_out, nwords * k, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(valid, h->bch_val, nwords, hipMemcpyDeviceToHost, h->stream));
+    if (nerrors) HIP_TRY(hipMemcpyAsync(nerrors, h->bch_err, nwords, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
 }
 
 // ---- reply generation: handle_response / handle_registration / handle_origination

@@ -160,6 +160,7 @@ struct CaptureArgs {
     uint32_t rec_cap;
     uint32_t *status;         // bit 2: record list overflow
     uint32_t majority;        // decode mode (AMPS_RECC_FLAG_MAJORITY)
+    uint8_t *burst_syms;      // optional [rec_cap][3374]: the captured symbols of record `slot` (AMPS_RECC_FLAG_KEEP_BURSTS)
 };
 
 __global__ __launch_bounds__(64) void recc_capture_kernel(CaptureArgs a)
@@ -189,6 +190,10 @@ __global__ __launch_bounds__(64) void recc_capture_kernel(CaptureArgs a)
         if (lane == 0) s_slot = atomicAdd(a.nrecords, 1u);
         __syncthreads();
         const uint32_t slot = s_slot;
+        if (slot < a.rec_cap && a.burst_syms) {
+            uint8_t *dst = a.burst_syms + (uint64_t)slot * AMPS_RECC_CAPTURE_SYMS;
+            for (int i = lane; i < AMPS_RECC_CAPTURE_SYMS; i += 64) dst[i] = s.sym[i];
+        }
         if (slot < a.rec_cap) decode_burst_wave(s, c, nc, a.records + slot, a.majority != 0);
         else { if (lane == 0) atomicOr(a.status, 4u); }
         __syncthreads();

@@ -2,12 +2,16 @@
 // as a stand-alone program.  Modes:
 //   recctest syms <file.u8>  [chunk]   u8 0/1 symbol file -> amps.recc -> amps.recc_decode
 //   recctest iq   <file.fc32> [chunk]  200 ksps interleaved fc32 -> amps.recc_fused -> amps.recc_decode
+//   recctest iqb  <file.fc32> [chunk]  the same through recc_fused's "bursts" port (the 3374-byte blob amps_recc publishes) instead of "records"
+//   recctest bank <file.u8>  [chunk] [C]  C channels in ONE gr::amps::recc_bank block: channel c = the symbol file delayed by 37 c symbols;
+//                                      every line is prefixed with the channel the burst came from
 //   recctest raw  <file.fc32> [chunk] [center_hz]   the flow graph's own capture format (grc/recctest.grc:591): 400 ksps fc32,
 //                                      channel at center_hz (default +160 kHz, :889-937) -> channel filter + fused chain on the GPU
 // Every message published on recc_decode's output ports is printed as one text line, which is what
 // tests/test_gpu_host_blocks.py compares with the oracle.
 #include <amps/recc.h>
 #include <amps/recc_decode.h>
+#include <amps/recc_bank.h>
 #include <amps/recc_fused.h>
 #include <cstdio>
 #include <cstdlib>
@@ -55,7 +59,7 @@ struct sink : gr::block {   // prints what ampsbs.grc would route to focc / fvc 
 
 int main(int argc, char **argv)
 {
-    if (argc < 3) { std::fprintf(stderr, "usage: %s syms|iq|raw <file> [chunk] [center_hz]\n", argv[0]); return 2; }
+    if (argc < 3) { std::fprintf(stderr, "usage: %s syms|iq|iqb|raw|bank <file> [chunk] [center_hz | C]\n", argv[0]); return 2; }
     const std::string mode = argv[1];
     const int chunk = argc > 3 ? std::atoi(argv[3]) : 4096;
     std::ifstream f(argv[2], std::ios::binary);
@@ -66,7 +70,39 @@ int main(int argc, char **argv)
         auto snk = std::make_shared<sink>();
         for (const char *p : { "focc_words", "fvc_words", "audio_mute", "fvc_mute", "command_out" }) gr::msg_connect(dec, p, snk, p);
         gr_vector_void_star outs;
-        if (mode == "syms") {
+        if (mode == "bank") {
+            const int C = argc > 4 ? std::atoi(argv[4]) : 8;
+            auto src = gr::amps::recc_bank::make(C);
+            // demultiplex: (channel, blob) -> print the channel, hand the blob to the one recc_decode
+            struct demux : gr::block {
+                std::shared_ptr<gr::basic_block> dec;
+                demux() : gr::block("demux", gr::io_signature::make(0, 0, 0), gr::io_signature::make(0, 0, 0))
+                {
+                    message_port_register_in(pmt::mp("bursts"));
+                    set_msg_handler(pmt::mp("bursts"), [this](pmt::pmt_t m) {
+                        std::printf("MSG channel %ld\n", pmt::to_long(pmt::car(m)));
+                        dec->dispatch("bursts", pmt::cdr(m));
+                    });
+                }
+                int general_work(int n, gr_vector_int &, gr_vector_const_void_star &, gr_vector_void_star &) override { return n; }
+            };
+            auto dm = std::make_shared<demux>();
+            dm->dec = dec;
+            gr::msg_connect(src, "bursts", dm, "bursts");
+            std::vector<std::vector<char>> chans((size_t)C);
+            for (int c = 0; c < C; c++) {                       // channel c: 37 c idle symbols in front of the file
+                chans[c].assign((size_t)37 * c, 0);
+                chans[c].insert(chans[c].end(), data.begin(), data.end());
+                chans[c].resize(data.size() + (size_t)37 * C, 0);
+            }
+            const size_t total = data.size() + (size_t)37 * C;
+            for (size_t off = 0; off < total; off += (size_t)chunk) {
+                int n = (int)std::min<size_t>((size_t)chunk, total - off);
+                gr_vector_const_void_star ins;
+                for (int c = 0; c < C; c++) ins.push_back(chans[c].data() + off);
+                if (src->work(n, ins, outs) != 0) return 1;
+            }
+        } else if (mode == "syms") {
             auto src = gr::amps::recc::make();
             gr::msg_connect(src, "bursts", dec, "bursts");
             for (size_t off = 0; off < data.size(); off += (size_t)chunk) {
@@ -77,7 +113,7 @@ int main(int argc, char **argv)
         } else {
             const double center = argc > 4 ? std::atof(argv[4]) : 160e3;
             auto src = mode == "raw" ? gr::amps::recc_fused::make(10, 400e3, center, 2) : gr::amps::recc_fused::make(10);
-            gr::msg_connect(src, "records", dec, "records");
+            if (mode == "iqb") gr::msg_connect(src, "bursts", dec, "bursts"); else gr::msg_connect(src, "records", dec, "records");
             const size_t ns = data.size() / 8;
             for (size_t off = 0; off < ns; off += (size_t)chunk) {
                 int n = (int)std::min<size_t>((size_t)chunk, ns - off);

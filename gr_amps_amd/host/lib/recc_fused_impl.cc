@@ -1,9 +1,11 @@
-// recc_fused_impl.cc -- gr::amps::recc_fused: complex baseband in, "bursts"-compatible messages out.
+// recc_fused_impl.cc -- gr::amps::recc_fused: complex baseband in; on "bursts" the same 3374-byte symbol blob gr::amps::recc
+// publishes (lib/recc_impl.cc:126), on "records" the already decoded record.
 // Replaces quadrature_demod_cf -> clock_recovery_mm_ff -> binary_slicer_fb -> amps_recc with the fused
 // MI355X kernel (amps_recc_push_iq / amps_recc_drain).
 #include <amps/recc_fused.h>
 #include <cstdio>
 #include <stdexcept>
+#include <vector>
 #include "amps_recc.h"
 
 namespace gr {
@@ -12,20 +14,23 @@ namespace amps {
 class recc_fused_impl : public recc_fused {
     amps_recc_t *d_handle;
     bool d_raw;
+    std::vector<unsigned char> d_bursts;
     static const int kMaxPush = 1 << 20;
+    static const int kMaxRecs = 64;
 
 public:
     recc_fused_impl(int sps, double xlate_rate, double xlate_center, int xlate_decim)
         : gr::sync_block("recc_fused", gr::io_signature::make(1, 1, 2 * sizeof(float)), gr::io_signature::make(0, 0, 0)), d_handle(nullptr),
-          d_raw(xlate_rate > 0.0)
+          d_raw(xlate_rate > 0.0), d_bursts((size_t)kMaxRecs * AMPS_RECC_CAPTURE_SYMS)
     {
         amps_recc_cfg_t cfg = {};
         cfg.struct_size = sizeof(cfg);
         cfg.n_channels = 1;
         cfg.samples_per_symbol = (uint32_t)sps;
         cfg.max_samples_per_push = kMaxPush;
-        cfg.max_bursts = 64;
+        cfg.max_bursts = kMaxRecs;
         cfg.device = -1;
+        cfg.flags = AMPS_RECC_FLAG_KEEP_BURSTS;               // the captured symbols travel with the record
         int rc = amps_recc_create(&d_handle, &cfg);
         if (rc != 0) throw std::runtime_error(std::string("amps::recc_fused: ") + amps_recc_strerror(rc));
         if (d_raw) {
@@ -40,7 +45,8 @@ public:
                 throw std::runtime_error(std::string("amps::recc_fused (xlate): ") + amps_recc_strerror(rc));
             }
         }
-        message_port_register_out(pmt::mp("records"));
+        message_port_register_out(pmt::mp("bursts"));          // what amps_recc publishes: connects to amps_recc_decode unchanged
+        message_port_register_out(pmt::mp("records"));         // the same burst already decoded (recc_decode accepts it too)
     }
     ~recc_fused_impl() { amps_recc_destroy(d_handle); }
 
@@ -54,11 +60,14 @@ public:
             int rc = d_raw ? amps_recc_push_raw(d_handle, in + 2 * (size_t)done, (size_t)n, (size_t)n, AMPS_MEM_HOST)
                            : amps_recc_push_iq(d_handle, in + 2 * (size_t)done, (size_t)n, (size_t)n, AMPS_MEM_HOST);
             if (rc != 0) { std::fprintf(stderr, "amps::recc_fused: %s\n", amps_recc_strerror(rc)); return WORK_DONE; }
-            amps_recc_burst_t recs[64];
+            amps_recc_burst_t recs[kMaxRecs];
             size_t nrec = 0;
-            rc = amps_recc_drain(d_handle, recs, 64, &nrec);
+            rc = amps_recc_drain_bursts(d_handle, recs, d_bursts.data(), kMaxRecs, &nrec);
             if (rc != 0) { std::fprintf(stderr, "amps::recc_fused: %s\n", amps_recc_strerror(rc)); return WORK_DONE; }
-            for (size_t i = 0; i < nrec; i++) message_port_pub(pmt::mp("records"), pmt::mp(&recs[i], sizeof(recs[i])));
+            for (size_t i = 0; i < nrec; i++) {
+                message_port_pub(pmt::mp("bursts"), pmt::mp(d_bursts.data() + i * AMPS_RECC_CAPTURE_SYMS, AMPS_RECC_CAPTURE_SYMS));
+                message_port_pub(pmt::mp("records"), pmt::mp(&recs[i], sizeof(recs[i])));
+            }
             done += n;
         }
         consume_each(noutput_items);

@@ -62,6 +62,8 @@ extern "C" {
                                                Im(x[n] conj(x[n-sps])), the telescoped form of discriminator + boxcar) */
 #define AMPS_RECC_FLAG_SLICER_SINE  0x10u /* IQ / wideband seams: slicer spec C (boxcar over Im(x[n] conj(x[n-1])): spec A without the
                                                arctangent).  At most one of the two SLICER flags may be set */
+#define AMPS_RECC_FLAG_KEEP_BURSTS  0x20u /* IQ / wideband seams: also keep the 3374 captured symbol bytes of every burst (what
+                                               gr::amps::recc publishes on "bursts", lib/recc_impl.cc:126) for amps_recc_drain_bursts */
 #define AMPS_RECC_FLAG_MAJORITY     0x2u /* decode mode "majority" instead of "reference" (SURVEY.md 8f.2), see below */
 
 /* message classes, the branches of lib/recc_decode_impl.cc:108-168 */
@@ -258,6 +260,10 @@ int amps_recc_drain(amps_recc_t *h, amps_recc_burst_t *out, size_t cap, size_t *
  * (-EBUSY otherwise); amps_recc_drain == drain_begin + drain_end. */
 int amps_recc_drain_begin(amps_recc_t *h);
 int amps_recc_drain_end(amps_recc_t *h, amps_recc_burst_t *out, size_t cap, size_t *nout);
+/* amps_recc_drain that also hands out the captured symbols of every record, bursts_out[i] = the 3374 bytes (0/1) the reference's
+ * recc block would have published for record i ([cap][3374] host bytes; handle created with AMPS_RECC_FLAG_KEEP_BURSTS, -ENOSYS
+ * otherwise).  decode_bursts(bursts_out[i]) gives out[i] again (position and channel aside). */
+int amps_recc_drain_bursts(amps_recc_t *h, amps_recc_burst_t *out, uint8_t *bursts_out, size_t cap, size_t *nout);
 
 /* test/diagnostic taps (not on the hot path): FM-demod floats and sliced symbol bits of one
  * channel for the last push_iq() call.  demod/soft/hard are host arrays of length n (may be NULL). */

@@ -1,8 +1,9 @@
 """world_size-2 gloo tests of the multi-GPU form of the path: channels are
 partitioned across ranks, there is no collective inside the data path, and the gathered records of
-the ranks equal the single-process result.  The HIP engine cannot run here (no GPU), so each rank
-computes its shard with the CPU oracle -- the test covers the sharding, broadcast and gather logic
-of gr_amps_amd/shard.py that bench.py and a multi-GPU deployment use."""
+the ranks equal the single-process result.  Where a GPU is visible each rank runs its shard on the HIP
+engine (capi.Recc on its own device: rank % device_count); on a box without GPUs (this container) the
+shard is computed with the CPU oracle, and the test covers the sharding, broadcast and gather logic of
+gr_amps_amd/shard.py that bench.py and a multi-GPU deployment use."""
 import os
 import sys
 
@@ -46,7 +47,13 @@ def _worker(rank, world, port, mode, q):
         else:                    # every rank already holds (only) its own channels
             iq = np.stack([synth.make_channel_block(N, 1, seed=900 + c)[0] for c in range(C)])
         lo, hi = shard.shard_range(C, rank, world)
-        local = oracle.fused_push_all(iq[lo:hi])          # rank-local channel numbering 0..hi-lo
+        if torch.cuda.is_available():                     # the product path: this rank's channel group on its own GPU
+            from gr_amps_amd import capi
+            with capi.Recc(n_channels=hi - lo, sps=10, max_samples=N, max_bursts=64, device=rank % torch.cuda.device_count()) as r:
+                r.push_iq(np.ascontiguousarray(iq[lo:hi]))
+                local = r.drain()
+        else:
+            local = oracle.fused_push_all(iq[lo:hi])      # rank-local channel numbering 0..hi-lo
         allrec = shard.gather_records(local, oracle.BURST_DTYPE, channel_offset=lo, dst=0)
         if rank == 0:
             ref = oracle.fused_push_all(np.stack([synth.make_channel_block(N, 1, seed=900 + c)[0] for c in range(C)]))

@@ -84,3 +84,61 @@ def test_recctest_raw_capture_through_channel_filter_and_recc_fused(gpu, tmp_pat
     it = iter(got)
     assert all(line in it for line in want), (want, got)
     assert len(got) >= len(want)
+
+
+def test_recc_fused_bursts_port_carries_what_amps_recc_publishes(gpu, tmp_path):
+    """recc_fused's "bursts" port (the header's contract, matching lib/recc_impl.cc:126): the 3374-byte symbol blob, decoded
+    by recc_decode, must produce exactly what the already decoded "records" port produces"""
+    iq, truth = synth.make_channel_block(4 * 40000, 4, seed=34)
+    p = tmp_path / "recc200k.fc32"
+    iq.tofile(p)
+    via_records = _run("iq", str(p), 10000)
+    via_bursts = _run("iqb", str(p), 10000)
+    assert via_bursts == via_records and len(via_records) >= 4
+
+
+def test_drain_bursts_symbols_decode_back_to_the_records(gpu):
+    from gr_amps_amd import capi
+    iq, truth = synth.make_channel_block(3 * 40000, 3, seed=35)
+    with capi.Recc(n_channels=1, sps=10, max_samples=iq.size, max_bursts=16, keep_bursts=True) as r:
+        r.push_iq(iq[None, :])
+        recs, syms = r.drain_bursts()
+        again = r.decode_bursts(syms)
+    assert len(recs) == len(truth) == 3 and syms.shape == (3, 3374) and set(np.unique(syms)) <= {0, 1}
+    for f in ("dcc", "valid", "word_raw", "word_dec", "msg_class", "min", "esn", "dialed", "manch_bad", "first_valid_rep"):
+        assert np.array_equal(recs[f], again[f]), f
+    want = oracle.fused_push_all(iq[None, :])
+    assert recs.tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("chunk", [4096, 1000])
+def test_recc_bank_block_equals_one_recc_block_per_channel(gpu, tmp_path, chunk):
+    """gr::amps::recc_bank: C channels in one block, one launch per work(); every channel must publish what a lone
+    gr::amps::recc (= the reference's work() replica) publishes on that channel's stream with the same chunk schedule"""
+    rng = np.random.default_rng(36)
+    bursts, off = [], 3000
+    for _ in range(3):
+        _, _, _, _, words = synth.random_message(rng)
+        bursts.append((off, synth.burst_bits(words, dcc=int(rng.integers(0, 4)), rng=rng)))
+        off += 3456 + 74 + 8191 + int(rng.integers(100, 900))
+    s = synth.symbol_stream(off + 9000, bursts, rng)
+    p = tmp_path / "recc.syms"
+    s.tofile(p)
+    C = 6
+    got = _run("bank", str(p), chunk) if False else None
+    _, exe = build_host()
+    out = subprocess.run([exe, "bank", str(p), str(chunk), str(C)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    got = [l for l in out.stdout.splitlines() if l.startswith("MSG ")]
+    # expected: per channel c the stream is the file delayed by 37 c symbols; calls interleave channel-ordered per work() call
+    total = s.size + 37 * C
+    chans = [np.concatenate([np.zeros(37 * c, np.uint8), s, np.zeros(37 * (C - c), np.uint8)]) for c in range(C)]
+    refs = [oracle.Recc() for _ in range(C)]
+    want = []
+    for o in range(0, total, chunk):
+        for c in range(C):
+            b = refs[c].work(chans[c][o:o + chunk])
+            if b is not None:
+                want.append("MSG channel %d" % c)
+                want += _expected_lines(oracle.decode_bursts(b[None, :]))
+    assert got == want and sum(1 for l in got if l.startswith("MSG channel")) == 3 * C
