@@ -250,27 +250,37 @@ int front_depth()   // tiles in flight per wave; AMPS_RECC_DEPTH overrides for e
     if (!v) { const char *e = std::getenv("AMPS_RECC_DEPTH"); v = e ? std::atoi(e) : 1; if (v < 1 || v > 3) v = 1; }   // measured: 1 -> 0.347 ms, 2 -> 0.370, 3 -> 0.452 (832 ch x 2^18)
     return v;
 }
-template <int SPS> int front_blocks_per_cu()
+template <int SPS> int front_blocks_per_cu(int slicer, bool tol)   // of the kernel launch_front<SPS> will pick
 {
     int n = 0;
     hipError_t e;
-    switch (front_depth()) {
+    const int depth = front_depth();
+    if (slicer == AMPS_SLICER_PRODUCT) {
+        if (tol) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, recc_front_kernel<SPS, 1, false, true, AMPS_SLICER_PRODUCT>, 256, 0);
+        else if (depth == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, recc_front_kernel<SPS, 2, false, false, AMPS_SLICER_PRODUCT>, 256, 0);
+        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, recc_front_kernel<SPS, 1, false, false, AMPS_SLICER_PRODUCT>, 256, 0);
+    } else if (slicer == AMPS_SLICER_SINE) {
+        if (tol) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, recc_front_kernel<SPS, 1, false, true, AMPS_SLICER_SINE>, 256, 0);
+        else if (depth == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, recc_front_kernel<SPS, 2, false, false, AMPS_SLICER_SINE>, 256, 0);
+        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, recc_front_kernel<SPS, 1, false, false, AMPS_SLICER_SINE>, 256, 0);
+    } else if (tol) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, recc_front_kernel<SPS, 1, false, true>, 256, 0);
+    else switch (depth) {
     case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, recc_front_kernel<SPS, 2>, 256, 0); break;
     case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, recc_front_kernel<SPS, 3>, 256, 0); break;
     default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, recc_front_kernel<SPS, 1>, 256, 0); break;
     }
     return (e == hipSuccess && n > 0) ? n : 2;
 }
-int front_blocks_per_cu_for(uint32_t sps)
+int front_blocks_per_cu_for(uint32_t sps, int slicer, bool tol)
 {
     switch (sps) {
-    case 3: return front_blocks_per_cu<3>();
-    case 4: return front_blocks_per_cu<4>();
-    case 5: return front_blocks_per_cu<5>();
-    case 6: return front_blocks_per_cu<6>();
-    case 8: return front_blocks_per_cu<8>();
-    case 10: return front_blocks_per_cu<10>();
-    case 12: return front_blocks_per_cu<12>();
+    case 3: return front_blocks_per_cu<3>(slicer, tol);
+    case 4: return front_blocks_per_cu<4>(slicer, tol);
+    case 5: return front_blocks_per_cu<5>(slicer, tol);
+    case 6: return front_blocks_per_cu<6>(slicer, tol);
+    case 8: return front_blocks_per_cu<8>(slicer, tol);
+    case 10: return front_blocks_per_cu<10>(slicer, tol);
+    case 12: return front_blocks_per_cu<12>(slicer, tol);
     default: return 2;
     }
 }
@@ -278,11 +288,13 @@ template <int SPS> void launch_front(const FrontArgs &fa, dim3 grid, hipStream_t
 {
     if (slicer == AMPS_SLICER_PRODUCT) {
         if (fa.tol) hipLaunchKernelGGL((recc_front_kernel<SPS, 1, false, true, AMPS_SLICER_PRODUCT>), grid, dim3(256), 0, s, fa);
+        else if (front_depth() == 2) hipLaunchKernelGGL((recc_front_kernel<SPS, 2, false, false, AMPS_SLICER_PRODUCT>), grid, dim3(256), 0, s, fa);
         else hipLaunchKernelGGL((recc_front_kernel<SPS, 1, false, false, AMPS_SLICER_PRODUCT>), grid, dim3(256), 0, s, fa);
         return;
     }
     if (slicer == AMPS_SLICER_SINE) {
         if (fa.tol) hipLaunchKernelGGL((recc_front_kernel<SPS, 1, false, true, AMPS_SLICER_SINE>), grid, dim3(256), 0, s, fa);
+        else if (front_depth() == 2) hipLaunchKernelGGL((recc_front_kernel<SPS, 2, false, false, AMPS_SLICER_SINE>), grid, dim3(256), 0, s, fa);
         else hipLaunchKernelGGL((recc_front_kernel<SPS, 1, false, false, AMPS_SLICER_SINE>), grid, dim3(256), 0, s, fa);
         return;
     }
@@ -487,7 +499,7 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
         // span of the flattened (channel, tile) space.  A channel is covered by at most max_waves/C + 2 segments.
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { amps_recc_destroy(h); return -ENODEV; }
-        h->max_waves = (uint32_t)prop.multiProcessorCount * 4u * (uint32_t)front_blocks_per_cu_for(h->sps);   // exactly one resident round
+        h->max_waves = (uint32_t)prop.multiProcessorCount * 4u * (uint32_t)front_blocks_per_cu_for(h->sps, h->slicer, cfg->sync_tolerance != 0);   // exactly one resident round
         {
             int nb = 0;
             hipError_t e;

@@ -111,12 +111,14 @@ __global__ __launch_bounds__(THREADS) void recc_resolve_kernel(ResolveArgs a)
         __syncthreads();
         const uint32_t total = s_total < RESOLVE_LDS_HITS ? s_total : RESOLVE_LDS_HITS;
         // ---- hold-off walk.  The rule is sequential (a hit is dropped iff it starts inside the hold-off of the last
-        // ACCEPTED hit), but a hit that starts at least one hold-off after the CENTRE of its predecessor is outside every
-        // earlier burst whatever was accepted (hits are ordered, so every earlier centre is <= that one): it is accepted
-        // unconditionally and heads a new chain.  Chains are walked independently, one lane each; real traffic has one
+        // ACCEPTED hit), but a hit that starts at least one hold-off after the latest possible CENTRE of any earlier hit is
+        // outside every earlier burst whatever was accepted: hits are ordered by their START and a run is at most 256 phases
+        // long, so every earlier centre is below start[j-1] + 128 (the centre of hit j-1 itself is no bound: an earlier,
+        // longer run can end later -- tolerant sync lengthens runs).  Such a hit, if it also lies beyond the hold-off carried
+        // in from the previous batch / push, is accepted unconditionally and heads a new chain.  Chains are walked independently, one lane each; real traffic has one
         // hit per chain (one lane did all of it before: 125 ns per hit, 0.09 ms for the 745 bursts of one channel x 2^26).
         for (uint32_t j = tid; j < total; j += THREADS)
-            s_head[j] = (j == 0) || ((s_hits[j] >> 8) >= centre(s_hits[j - 1]) + span_hold);
+            s_head[j] = (j == 0) || ((s_hits[j] >> 8) >= (s_hits[j - 1] >> 8) + 128 + span_hold && (s_hits[j] >> 8) >= next_allowed);
         __syncthreads();
         for (uint32_t j = tid; j < total; j += THREADS) {
             if (!s_head[j]) continue;
