@@ -260,11 +260,10 @@ __device__ __forceinline__ void chz_p2_t(cf2 *A, const cf2 *tab, const cf2 (&twr
         for (int r = 0; r < 16; r++) u[r] = src[68 * r];
     }
     if constexpr (REGS) {
-        // 12-wave kernel: the FFT waves have the registers for the 15 twiddles W_64^{r k} (loop invariant).  From the LDS
-        // table the compiler reads them one pair at a time between the multiplies -- eight exposed LDS latencies per pass
-        // (measured with s_memtime: pass 2 took 2950 cycles per frame against 1780 for pass 3, which has its twiddles in registers)
-#pragma unroll
-        for (int r = 1; r < 16; r++) u[r] = cmul(u[r], twr[r - 1]);
+        // 12-wave kernel: the fold waves have already applied the input twiddles W_64^{r k} (chz_fold2_ring).  (Read from the
+        // LDS table here, one pair at a time between the multiplies, they cost eight exposed LDS latencies per pass: measured
+        // with s_memtime, pass 2 took 2950 cycles per frame against 1780 for pass 3.)
+        (void)twr;
     } else {
         // The 15 twiddles are loop invariant; hoisted out of the batch loop they would pin 30 VGPRs the 4-wave kernel does
         // not have.  The empty asm hides the invariance of the index (laundering the POINTER instead turns the reads
@@ -682,7 +681,7 @@ __device__ __forceinline__ void chz_fold_taps2(cf2 (&acc)[2][4], const cf2 (&x0)
 // frames FA, FA+1 of a half-step (FA = 0: tap windows start at SA = 1 / SB = 0 and 1 / 1; FA = 2: 2 / 1 and 2 / 2), then the
 // radix-4 pass 1 of both -> A[FA], A[FA+1]
 template <int P, int BASE, int FA>
-__device__ __forceinline__ void chz_fold2_ring(const cf2 (&ring)[4][P + 4], const cf2 (&coef)[4][P / 2], cf2 *bufA, int t)
+__device__ __forceinline__ void chz_fold2_ring(const cf2 (&ring)[4][P + 4], const cf2 (&coef)[4][P / 2], const cf2 (&tw1)[3], cf2 *bufA, int t)
 {
     constexpr int R = P + 4;
     constexpr int S[2][2] = { { FA == 0 ? 1 : 2, FA == 0 ? 0 : 1 }, { FA == 0 ? 1 : 2, FA == 0 ? 1 : 2 } };   // [frame][jb >= 2]
@@ -705,15 +704,17 @@ __device__ __forceinline__ void chz_fold2_ring(const cf2 (&ring)[4][P + 4], cons
     for (int f = 0; f < 2; f++) {
         cf2 o[4];
         dft4(acc[f][0], acc[f][1], acc[f][2], acc[f][3], o);     // radix 4, p = 1: no twiddles
+        // the input twiddles of pass 2 (element 4 t + k1 is its point r = t >> 4 of lane 4 (t & 15) + k1: W_64^{r k1}) are applied
+        // HERE: the fold waves wait at the barriers more than half of the time, the FFT waves are the critical path of a time step
         cf2 *d = bufA + (FA + f) * CHZ_FB + t;
-        d[chz_pos1(0, 0)] = o[0]; d[chz_pos1(0, 1)] = o[1]; d[chz_pos1(0, 2)] = o[2]; d[chz_pos1(0, 3)] = o[3];
+        d[chz_pos1(0, 0)] = o[0]; d[chz_pos1(0, 1)] = cmul(o[1], tw1[0]); d[chz_pos1(0, 2)] = cmul(o[2], tw1[1]); d[chz_pos1(0, 3)] = cmul(o[3], tw1[2]);
     }
 }
 template <int P, int BASE>
-__device__ __forceinline__ void chz_fold_half_ring(const cf2 (&ring)[4][P + 4], const cf2 (&coef)[4][P / 2], cf2 *bufA, int t)
+__device__ __forceinline__ void chz_fold_half_ring(const cf2 (&ring)[4][P + 4], const cf2 (&coef)[4][P / 2], const cf2 (&tw1)[3], cf2 *bufA, int t)
 {
-    chz_fold2_ring<P, BASE, 0>(ring, coef, bufA, t);
-    chz_fold2_ring<P, BASE, 2>(ring, coef, bufA, t);
+    chz_fold2_ring<P, BASE, 0>(ring, coef, tw1, bufA, t);
+    chz_fold2_ring<P, BASE, 2>(ring, coef, tw1, bufA, t);
 }
 // the two samples frame F + g brings for this thread go to branches 2 (g & 1) + {0, 1}, logical element ELEM + (g >> 1).
 // FAST (the four frames lie inside the new block): the eight loads are issued as inline asm, so that the compiler does not
@@ -860,7 +861,6 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
     constexpr bool IQ = MODE == CHZ12_IQ;
     constexpr int SL = IQ ? AMPS_SLICER_ATAN_BOXCAR : MODE;
     __shared__ cf2 bufA[2][NB * CHZ_FB];
-    __shared__ cf2 tab[64];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -871,7 +871,6 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
     // (zeros): they only prime the delay lines for the last four, which are exact (the carry holds L - D + 4 D samples)
     const int64_t fs = IQ ? f0 : f0 - NB;
     const int nbatch = (int)((f1 - fs + NB - 1) / NB);
-    if (tid < 64) tab[tid] = chz_twiddle((tid >> 2) * (tid & 3), 64);   // tab[4 r + k]
 
     // time step s: the fold waves produce batch s into bufA[s & 1] while the FFT waves consume batch s - 1 from the other
     // half; both roles pass the same two barriers per step
@@ -884,6 +883,9 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
         for (int j = 0; j < 4; j++)
 #pragma unroll
             for (int q = 0; q < P; q += 2) coef[j][q / 2] = (cf2){ a.taps[t + 256 * j + q * M], a.taps[t + 256 * j + (q + 1) * M] };
+        cf2 tw1[3];                                               // pass 2's input twiddles of this thread's outputs k1 = 1..3
+#pragma unroll
+        for (int k1 = 1; k1 < 4; k1++) tw1[k1 - 1] = chz_twiddle((t >> 4) * k1, 64);
         cf2 ring[4][P + 4];                                       // delay lines + the inputs of this and the next half-step
         {
             const int64_t vend = fs * D;                          // multiple of M (fs is even)
@@ -896,7 +898,7 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
         }
         chz_load_half_ring<P, 0, P, false>(ring, in, fs, t);
         chz_load_half_ring<P, 0, P + 2, false>(ring, in, fs + CHZ_BATCH, t);
-        __syncthreads();                                          // tab
+        __syncthreads();                                          // both roles start together
         // one half-step = four frames: fold them, then load the frames of the half-step after next into the two slots that
         // just died.  A load has eight frames (~4 us) to arrive: with four frames of lead, as in the 4-wave kernels, the fold
         // waves were the critical path (4 waves x 8 loads x 512 B = 16 KB in flight per CU do not cover the HBM latency under
@@ -907,7 +909,7 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
                 const int64_t F = fs + (int64_t)NB * sidx + CHZ_BATCH * half;
                 cf2 *dst = bufA[sidx & 1] + CHZ_BATCH * half * CHZ_FB;
                 chz_ring_wait<P, BASE>(ring);
-                chz_fold_half_ring<P, BASE>(ring, coef, dst, t);
+                chz_fold_half_ring<P, BASE>(ring, coef, tw1, dst, t);
                 if (in.batch_in_block(F + NB)) chz_load_half_ring<P, BASE, P + 4, true>(ring, in, F + NB, t);
                 else chz_load_half_ring<P, BASE, P + 4, false>(ring, in, F + NB, t);   // generic: zero beyond the data
             }
@@ -929,9 +931,10 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
         // ------------------------------------------------------------------ FFT role
         const int u = tid - 256;                                  // 0..511: owns bins u and u + 512
         const int wf = wave - 4;                                  // frame of the batch this wave transforms
-        cf2 tw2[15], tw34[15];                                    // twiddles of the two radix-16 passes: W_64^{r (lane & 3)}, W_1024^{r lane}
+        cf2 tw34[15];                                             // twiddles of the second radix-16 pass: W_1024^{r lane}
 #pragma unroll
-        for (int r = 1; r < 16; r++) { tw2[r - 1] = chz_twiddle(r * (lane & 3), 64); tw34[r - 1] = chz_twiddle(r * lane, 1024); }
+        for (int r = 1; r < 16; r++) tw34[r - 1] = chz_twiddle(r * lane, 1024);
+        const cf2 tw2[15] = {};                                   // (pass 2's are applied by the fold waves)
         ChzSlice2<SL> S;
         S.reset();
         uint32_t hold[2][4] = {};                                 // finished ring words of the two bins waiting for their 16-byte store
@@ -940,12 +943,12 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
         uint32_t ch[2];
 #pragma unroll
         for (int j = 0; j < 2; j++) ch[j] = ((uint32_t)(u + 512 * j) - a.first_bin) & (M - 1);
-        __syncthreads();                                          // tab
+        __syncthreads();                                          // both roles start together
         for (int s = 0; s <= nbatch; s++) {
             cf2 *A = bufA[(s - 1) & 1];
             if (s >= 1) {
                 cf2 *Af = A + wf * CHZ_FB;
-                chz_p2_t<true>(Af, tab, tw2, lane);
+                chz_p2_t<true>(Af, nullptr, tw2, lane);
                 chz_p34(Af, tw34, lane);
             }
             __syncthreads();
