@@ -15,6 +15,7 @@ SPECS = ("atan", "sine", "product")
 
 
 def score(recs, truth_by_key, key):
+    """truth_by_key: {(channel, MIN): (MIN, sent words)}; a record counts once, under its channel and decoded MIN"""
     found = len(recs)
     good = 0
     words = {}
@@ -42,13 +43,13 @@ for snr in (30, 24, 18, 15, 12, 10, 8):
         for i, (off, kind, min10, esn, dialed, wds) in enumerate(t):
             truth[(c, i)] = (min10, wds, off)
     iq = np.stack(iq)
-    by_pos = {(c, off // 40000): (m, w) for (c, i), (m, w, off) in truth.items()}
+    by_pos = {(c, m): (m, w) for (c, i), (m, w, off) in truth.items()}
     res = {}
     for sp in SPECS:
         with capi.Recc(n_channels=C, sps=10, max_samples=N, max_bursts=1024, slicer=sp) as r:
             r.push_iq(iq)
             recs = r.drain()
-        res[sp] = score(recs, by_pos, lambda g: (int(g["channel"]), int(g["position"]) // 40000))
+        res[sp] = score(recs, by_pos, lambda g: (int(g["channel"]), g["min"].decode()))
     diff = [sum(1 for k, v in res["atan"][2].items() if res[sp][2].get(k) != v) for sp in ("sine", "product")]
     print("iq   %5d %4d | " % (snr, len(truth)) + " | ".join("%5d/%-5d" % res[sp][:2] for sp in SPECS) + " | %d, %d" % tuple(diff), flush=True)
 
@@ -59,7 +60,7 @@ for snr in (30, 24, 18, 15, 12, 10, 8):
     chans = rng.choice(Cw, size=min(NB, 64), replace=False)
     planted = [((first + int(c)) % 1024, int(rng.integers(20000, n - 3456 * 1536 - 20000))) for c in chans]
     x, truth = sw.make_wideband(n, planted, seed=8000 + snr, snr_db=float(snr))
-    tb = {(k - first) % 1024: (m, w) for (k, off), (kind, m, esn, dialed, w) in truth.items()}
+    tb = {((k - first) % 1024, m): (m, w) for (k, off), (kind, m, esn, dialed, w) in truth.items()}
     res = {}
     for sp in SPECS:
         with capi.Recc(n_channels=Cw, sps=3, max_samples=n // D + 72, max_bursts=1024, slicer=sp,
@@ -67,6 +68,6 @@ for snr in (30, 24, 18, 15, 12, 10, 8):
             r.push_wideband(x)
             r.push_wideband(np.zeros(64 * D, np.complex64))
             recs = r.drain()
-        res[sp] = score(recs, tb, lambda g: int(g["channel"]))
+        res[sp] = score(recs, tb, lambda g: (int(g["channel"]), g["min"].decode()))
     diff = [sum(1 for k, v in res["atan"][2].items() if res[sp][2].get(k) != v) for sp in ("sine", "product")]
     print("wide %5d %4d | " % (snr, len(tb)) + " | ".join("%5d/%-5d" % res[sp][:2] for sp in SPECS) + " | %d, %d" % tuple(diff), flush=True)
