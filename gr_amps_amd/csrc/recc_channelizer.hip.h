@@ -657,21 +657,23 @@ __global__ __launch_bounds__(256, P <= 8 ? 2 : 1) void chz_fused_kernel(ChzArgs 
 template <bool FIRST>
 __device__ __forceinline__ void chz_fold_taps2(cf2 (&acc)[2][4], const cf2 (&x0)[2][4], const cf2 (&x1)[2][4], const cf2 (&c)[4])
 {
-    // operands: 0..7 acc[f][jb] (f major), 8..15 x0, 16..23 x1, 24..27 c[0..3]
+    // operands: 0..7 acc[f][jb] (f major), 8..15 x0, 16..23 x1, 24..27 c[0..3].  Neighbouring instructions share their coefficient
+    // pair: a v_pk_fma_f32 with three distinct register-pair sources issues every 6.3 cycles, 5.6 when every second one repeats a
+    // source pair of its predecessor (scripts/ubench_pk3.hip, two waves per SIMD)
     if constexpr (FIRST) {
-        asm(CHZ_MUL_LO(0, 8, 26) CHZ_MUL_LO(1, 9, 27) CHZ_MUL_LO(2, 10, 24) CHZ_MUL_LO(3, 11, 25)
-            CHZ_MUL_LO(4, 12, 24) CHZ_MUL_LO(5, 13, 25) CHZ_MUL_LO(6, 14, 26) CHZ_MUL_LO(7, 15, 27)
-            CHZ_FMA_HI(0, 16, 26) CHZ_FMA_HI(1, 17, 27) CHZ_FMA_HI(2, 18, 24) CHZ_FMA_HI(3, 19, 25)
-            CHZ_FMA_HI(4, 20, 24) CHZ_FMA_HI(5, 21, 25) CHZ_FMA_HI(6, 22, 26) CHZ_FMA_HI(7, 23, 27)
+        asm(CHZ_MUL_LO(2, 10, 24) CHZ_MUL_LO(4, 12, 24) CHZ_MUL_LO(3, 11, 25) CHZ_MUL_LO(5, 13, 25)
+            CHZ_MUL_LO(0, 8, 26) CHZ_MUL_LO(6, 14, 26) CHZ_MUL_LO(1, 9, 27) CHZ_MUL_LO(7, 15, 27)
+            CHZ_FMA_HI(2, 18, 24) CHZ_FMA_HI(4, 20, 24) CHZ_FMA_HI(3, 19, 25) CHZ_FMA_HI(5, 21, 25)
+            CHZ_FMA_HI(0, 16, 26) CHZ_FMA_HI(6, 22, 26) CHZ_FMA_HI(1, 17, 27) CHZ_FMA_HI(7, 23, 27)
             : "=&v"(acc[0][0]), "=&v"(acc[0][1]), "=&v"(acc[0][2]), "=&v"(acc[0][3]), "=&v"(acc[1][0]), "=&v"(acc[1][1]), "=&v"(acc[1][2]), "=&v"(acc[1][3])
             : "v"(x0[0][0]), "v"(x0[0][1]), "v"(x0[0][2]), "v"(x0[0][3]), "v"(x0[1][0]), "v"(x0[1][1]), "v"(x0[1][2]), "v"(x0[1][3]),
               "v"(x1[0][0]), "v"(x1[0][1]), "v"(x1[0][2]), "v"(x1[0][3]), "v"(x1[1][0]), "v"(x1[1][1]), "v"(x1[1][2]), "v"(x1[1][3]),
               "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]));
     } else {
-        asm(CHZ_FMA_LO(0, 8, 26) CHZ_FMA_LO(1, 9, 27) CHZ_FMA_LO(2, 10, 24) CHZ_FMA_LO(3, 11, 25)
-            CHZ_FMA_LO(4, 12, 24) CHZ_FMA_LO(5, 13, 25) CHZ_FMA_LO(6, 14, 26) CHZ_FMA_LO(7, 15, 27)
-            CHZ_FMA_HI(0, 16, 26) CHZ_FMA_HI(1, 17, 27) CHZ_FMA_HI(2, 18, 24) CHZ_FMA_HI(3, 19, 25)
-            CHZ_FMA_HI(4, 20, 24) CHZ_FMA_HI(5, 21, 25) CHZ_FMA_HI(6, 22, 26) CHZ_FMA_HI(7, 23, 27)
+        asm(CHZ_FMA_LO(2, 10, 24) CHZ_FMA_LO(4, 12, 24) CHZ_FMA_LO(3, 11, 25) CHZ_FMA_LO(5, 13, 25)
+            CHZ_FMA_LO(0, 8, 26) CHZ_FMA_LO(6, 14, 26) CHZ_FMA_LO(1, 9, 27) CHZ_FMA_LO(7, 15, 27)
+            CHZ_FMA_HI(2, 18, 24) CHZ_FMA_HI(4, 20, 24) CHZ_FMA_HI(3, 19, 25) CHZ_FMA_HI(5, 21, 25)
+            CHZ_FMA_HI(0, 16, 26) CHZ_FMA_HI(6, 22, 26) CHZ_FMA_HI(1, 17, 27) CHZ_FMA_HI(7, 23, 27)
             : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3])
             : "v"(x0[0][0]), "v"(x0[0][1]), "v"(x0[0][2]), "v"(x0[0][3]), "v"(x0[1][0]), "v"(x0[1][1]), "v"(x0[1][2]), "v"(x0[1][3]),
               "v"(x1[0][0]), "v"(x1[0][1]), "v"(x1[0][2]), "v"(x1[0][3]), "v"(x1[1][0]), "v"(x1[1][1]), "v"(x1[1][2]), "v"(x1[1][3]),
