@@ -1,7 +1,7 @@
 """Randomised differential cases for the fused IQ seam: GPU records vs the CPU model (oracle/fused_model.c), byte for byte.
 Random samples-per-symbol, channel count, SNR (8..30 dB), burst placement (incl. truncated bursts, damaged preambles and
 triggers inside a hold-off window), push schedule (sync drains, split drains, several pushes per drain), sync tolerance,
-host- or device-resident blocks.  Used by tests/test_gpu_fuzz.py and scripts/fuzz_parity.py.
+slicer spec (A / B / C of include/amps_recc_numerics.h), host- or device-resident blocks.  Used by tests/test_gpu_fuzz.py and scripts/fuzz_parity.py.
 
 History: the first campaign (150 cases) failed 48 times -- host-resident blocks pushed back to back without a drain in
 between could be overwritten in the device staging buffer while the previous push's kernels were still reading it (a
@@ -23,6 +23,7 @@ def build_case(case, seed0):
     C = int(rng.integers(1, 5))
     tol = int(rng.choice([0, 0, 0, 1, 2, 4, 8]))
     majority = bool(rng.integers(0, 4) == 0)
+    slicer = int(rng.choice([0, 0, 1, 2, 2]))              # numeric spec of the slicer: A (default), B, C
     specs, N = [], 0
     for _ in range(C):
         off, bursts = int(rng.integers(200, 5000)), []
@@ -40,17 +41,18 @@ def build_case(case, seed0):
     N = int(N)
     snr = float(rng.uniform(8, 30))
     iq = np.stack([synth.fsk_modulate(N, b, sps=sps, fs=20e3 * sps, snr_db=snr, rng=rng) for b in specs])
-    return rng, dict(sps=sps, C=C, tol=tol, majority=majority, snr=round(snr, 1), N=N), iq
+    return rng, dict(sps=sps, C=C, tol=tol, majority=majority, slicer=slicer, snr=round(snr, 1), N=N), iq
 
 
 def run_case(case, seed0, resident=False, keep_host=False):
     """returns (ok, info)"""
     rng, info, iq = build_case(case, seed0)
     sps, C, tol, N = info["sps"], info["C"], info["tol"], info["N"]
-    want = oracle.fused_push_all(iq, sps=sps, tolerance=tol, majority=info["majority"])
+    want = oracle.fused_push_all(iq, sps=sps, tolerance=tol, majority=info["majority"], slicer=info["slicer"])
     if resident:
         import torch
-    with capi.Recc(n_channels=C, sps=sps, max_samples=N, max_bursts=256, sync_tolerance=tol, majority=info["majority"]) as r:
+    with capi.Recc(n_channels=C, sps=sps, max_samples=N, max_bursts=256, sync_tolerance=tol, majority=info["majority"],
+                   slicer=("atan", "product", "sine")[info["slicer"]]) as r:
         off, recs, pipelined, open_, keep = 0, [], bool(rng.integers(0, 2)), False, []
         while off < N:
             b = int(min(N - off, rng.integers(1, max(2, N // 2))))

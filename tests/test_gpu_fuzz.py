@@ -32,9 +32,11 @@ def test_wideband_random_schedules_give_the_one_shot_records(gpu, seed):
     x, truth = sw.make_wideband(n, bursts, seed=100 + seed)
     wb = {"channels": 1024, "decim": 512, "taps_per_branch": 8, "first_channel": first}
 
+    spec = ("atan", "sine", "product")[seed % 3]               # the slicer spec under test rotates with the seed
+
     def run(schedule, unfused, tol, resident, mode):
         with capi.Recc(n_channels=C, sps=3, max_samples=n // D + 72, max_bursts=64, unfused_wideband=unfused,
-                       sync_tolerance=tol, wideband=wb) as r:
+                       sync_tolerance=tol, wideband=wb, slicer=spec) as r:
             off, recs, open_, keep = 0, [], False, []
             for m in schedule + [64 * D]:                      # the last block is silence: flushes the held-back frames
                 blk = x[off:off + m] if off < n else np.zeros(m, np.complex64)
