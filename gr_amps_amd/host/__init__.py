@@ -10,7 +10,7 @@ RECCTEST = os.path.join(_PKG, "recctest")
 
 
 def build_host(force=False):
-    srcs = [os.path.join(_HERE, "lib", f) for f in ("recc_impl.cc", "recc_decode_impl.cc", "recc_fused_impl.cc", "recc_bank_impl.cc")]
+    srcs = [os.path.join(_HERE, "lib", f) for f in ("recc_impl.cc", "recc_decode_impl.cc", "recc_fused_impl.cc", "recc_bank_impl.cc", "recc_wideband_impl.cc")]
     hdrs = [os.path.join(_HERE, "lib", "recc_impl.h"), os.path.join(_HERE, "lib", "recc_decode_impl.h"),
             os.path.join(_HERE, "gr_min", "gnuradio_min.h"), os.path.join(_ROOT, "include", "amps_recc.h")]
     app = os.path.join(_HERE, "apps", "recctest.cc")

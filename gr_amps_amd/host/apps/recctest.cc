@@ -5,6 +5,8 @@
 //   recctest iqb  <file.fc32> [chunk]  the same through recc_fused's "bursts" port (the 3374-byte blob amps_recc publishes) instead of "records"
 //   recctest bank <file.u8>  [chunk] [C]  C channels in ONE gr::amps::recc_bank block: channel c = the symbol file delayed by 37 c symbols;
 //                                      every line is prefixed with the channel the burst came from
+//   recctest wide <file.fc32> [chunk] [slicer]  one 30.72 Msps wideband capture -> gr::amps::recc_wideband (832 channels from bin 96); every
+//                                      burst's lines are prefixed with its channel; decoded through the "bursts" port
 //   recctest raw  <file.fc32> [chunk] [center_hz]   the flow graph's own capture format (grc/recctest.grc:591): 400 ksps fc32,
 //                                      channel at center_hz (default +160 kHz, :889-937) -> channel filter + fused chain on the GPU
 // Every message published on recc_decode's output ports is printed as one text line, which is what
@@ -13,6 +15,7 @@
 #include <amps/recc_decode.h>
 #include <amps/recc_bank.h>
 #include <amps/recc_fused.h>
+#include <amps/recc_wideband.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -59,7 +62,7 @@ struct sink : gr::block {   // prints what ampsbs.grc would route to focc / fvc 
 
 int main(int argc, char **argv)
 {
-    if (argc < 3) { std::fprintf(stderr, "usage: %s syms|iq|iqb|raw|bank <file> [chunk] [center_hz | C]\n", argv[0]); return 2; }
+    if (argc < 3) { std::fprintf(stderr, "usage: %s syms|iq|iqb|raw|bank|wide <file> [chunk] [center_hz | C | slicer]\n", argv[0]); return 2; }
     const std::string mode = argv[1];
     const int chunk = argc > 3 ? std::atoi(argv[3]) : 4096;
     std::ifstream f(argv[2], std::ios::binary);
@@ -100,6 +103,31 @@ int main(int argc, char **argv)
                 int n = (int)std::min<size_t>((size_t)chunk, total - off);
                 gr_vector_const_void_star ins;
                 for (int c = 0; c < C; c++) ins.push_back(chans[c].data() + off);
+                if (src->work(n, ins, outs) != 0) return 1;
+            }
+        } else if (mode == "wide") {
+            auto src = gr::amps::recc_wideband::make(832, 96, argc > 4 ? std::atoi(argv[4]) : 0);
+            struct demux : gr::block {
+                std::shared_ptr<gr::basic_block> dec;
+                demux() : gr::block("demux", gr::io_signature::make(0, 0, 0), gr::io_signature::make(0, 0, 0))
+                {
+                    message_port_register_in(pmt::mp("bursts"));
+                    set_msg_handler(pmt::mp("bursts"), [this](pmt::pmt_t m) {
+                        std::printf("MSG channel %ld\n", pmt::to_long(pmt::car(m)));
+                        dec->dispatch("bursts", pmt::cdr(m));
+                    });
+                }
+                int general_work(int n, gr_vector_int &, gr_vector_const_void_star &, gr_vector_void_star &) override { return n; }
+            };
+            auto dm = std::make_shared<demux>();
+            dm->dec = dec;
+            gr::msg_connect(src, "bursts", dm, "bursts");
+            std::vector<char> tail((size_t)64 * 512 * 8, 0);          // silence: flushes the frames the fused form holds back
+            data.insert(data.end(), tail.begin(), tail.end());
+            const size_t ns = data.size() / 8;
+            for (size_t off = 0; off < ns; off += (size_t)chunk) {
+                int n = (int)std::min<size_t>((size_t)chunk, ns - off);
+                gr_vector_const_void_star ins = { data.data() + 8 * off };
                 if (src->work(n, ins, outs) != 0) return 1;
             }
         } else if (mode == "syms") {

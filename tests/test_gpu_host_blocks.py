@@ -142,3 +142,29 @@ def test_recc_bank_block_equals_one_recc_block_per_channel(gpu, tmp_path, chunk)
                 want.append("MSG channel %d" % c)
                 want += _expected_lines(oracle.decode_bursts(b[None, :]))
     assert got == want and sum(1 for l in got if l.startswith("MSG channel")) == 3 * C
+
+
+def test_recc_wideband_block_decodes_the_band(gpu, tmp_path):
+    """gr::amps::recc_wideband: one 30.72 Msps capture file in, (channel, burst) pairs out, through recc_decode: the lines of
+    every planted burst, under its channel, as the C ABI's own records give them (ragged work() sizes)"""
+    from gr_amps_amd import capi, synth_wideband as sw
+    n = int(0.26 * sw.FS_WIDE) // 512 * 512
+    planted = [(96 + 7, 150000), (96 + 500, 90000), (96 + 831, 230000)]
+    x, truth = sw.make_wideband(n, planted, seed=41)
+    p = tmp_path / "band.fc32"
+    x.tofile(p)
+    with capi.Recc(n_channels=832, sps=3, max_samples=n // 512 + 72, max_bursts=64,
+                   wideband={"channels": 1024, "decim": 512, "taps_per_branch": 8, "first_channel": 96}) as r:
+        r.push_wideband(x)
+        r.push_wideband(np.zeros(64 * 512, np.complex64))
+        recs = r.drain()
+    assert sorted(int(g["channel"]) for g in recs) == [7, 500, 831]
+    want = []
+    for g in recs:                                   # the block publishes in (channel, position) order per work() call
+        want.append("MSG channel %d" % int(g["channel"]))
+        want += _expected_lines(recs[recs["channel"] == g["channel"]])
+    _, exe = build_host()
+    out = subprocess.run([exe, "wide", str(p), "777777"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    got = [l for l in out.stdout.splitlines() if l.startswith("MSG ")]
+    assert sorted(got) == sorted(want) and [l for l in got if l.startswith("MSG channel")] != []
