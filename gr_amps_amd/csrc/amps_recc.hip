@@ -331,9 +331,9 @@ int dispatch_front(uint32_t sps, const FrontArgs &fa, dim3 grid, hipStream_t s, 
 static void launch_resolve(amps_recc *h, const ResolveArgs &ra, hipStream_t s)
 {
     if (ra.tiles_per_channel / ra.span + 2 > (uint64_t)RESOLVE_THREADS)
-        hipLaunchKernelGGL(recc_resolve_kernel<RESOLVE_THREADS_WIDE>, dim3(h->C), dim3(RESOLVE_THREADS_WIDE), 0, s, ra);
+        hipLaunchKernelGGL((recc_resolve_kernel<RESOLVE_THREADS_WIDE, RESOLVE_LDS_HITS_WIDE>), dim3(h->C), dim3(RESOLVE_THREADS_WIDE), 0, s, ra);
     else
-        hipLaunchKernelGGL(recc_resolve_kernel<RESOLVE_THREADS>, dim3(h->C), dim3(RESOLVE_THREADS), 0, s, ra);
+        hipLaunchKernelGGL((recc_resolve_kernel<RESOLVE_THREADS, RESOLVE_LDS_HITS>), dim3(h->C), dim3(RESOLVE_THREADS), 0, s, ra);
 }
 
 int run_iq_device(amps_recc *h, const float2 *iq, uint64_t ld, uint32_t nsamp)

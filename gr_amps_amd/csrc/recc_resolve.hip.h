@@ -38,19 +38,22 @@ struct ResolveArgs {
 
 constexpr int RESOLVE_THREADS = 256;       // many channels, few segments each
 constexpr int RESOLVE_THREADS_WIDE = 1024; // few channels, thousands of segments each (one channel x 2^26 samples)
-constexpr int RESOLVE_LDS_HITS = 2048;
+constexpr int RESOLVE_LDS_HITS = 512;        // hits walked per pass of the narrow kernel (10 KB of LDS instead of 38: four workgroups per CU become sixteen)
+constexpr int RESOLVE_LDS_HITS_WIDE = 2048;
 
 // One workgroup per channel.  The hit lists of a channel's wave segments are ordered but scattered
 // (up to thousands of segments when one channel is pushed 2^26 samples at a time): 256 (or 1024) lanes compact them into
 // LDS with a block-wide prefix sum (coalesced count loads, independent hit loads); the hold-off walk then runs on LDS,
 // split into independent chains (see below).  0.72 ms -> 0.09 (LDS, one lane) -> parallel chains, for one channel x 2^26.
-template <int THREADS>
+// A batch of THREADS segments with more hits than the LDS window holds is walked in several passes (the hold-off state
+// carries from pass to pass exactly as it does from batch to batch), so no hit count overflows this kernel.
+template <int THREADS, int HITS>
 __global__ __launch_bounds__(THREADS) void recc_resolve_kernel(ResolveArgs a)
 {
-    __shared__ uint64_t s_hits[RESOLVE_LDS_HITS];
+    __shared__ uint64_t s_hits[HITS];
     __shared__ uint32_t s_scan[THREADS];
-    __shared__ uint64_t s_acc[RESOLVE_LDS_HITS + 1];               // +1: the pending capture of an earlier push
-    __shared__ uint8_t  s_head[RESOLVE_LDS_HITS], s_accf[RESOLVE_LDS_HITS];
+    __shared__ uint64_t s_acc[HITS + 1];                           // +1: the pending capture of an earlier push
+    __shared__ uint8_t  s_head[HITS], s_accf[HITS];
     __shared__ uint64_t s_na_out, s_pend;
     __shared__ uint32_t s_total, s_nacc, s_base;
     const int c = blockIdx.x, tid = threadIdx.x;
@@ -93,7 +96,6 @@ __global__ __launch_bounds__(THREADS) void recc_resolve_kernel(ResolveArgs a)
         const uint32_t ch = cb + tid;
         const uint32_t n = ch < nchunks ? cnt[ch] : 0u;
         s_scan[tid] = n;
-        if (tid == 0) { s_pend = ~0ull; s_na_out = next_allowed; }
         __syncthreads();
         for (int off = 1; off < THREADS; off <<= 1) {       // Hillis-Steele inclusive scan
             uint32_t v = tid >= off ? s_scan[tid - off] : 0u;
@@ -103,48 +105,55 @@ __global__ __launch_bounds__(THREADS) void recc_resolve_kernel(ResolveArgs a)
         }
         const uint32_t excl = s_scan[tid] - n;
         if (tid == THREADS - 1) s_total = s_scan[tid];
+        __syncthreads();
+        const uint32_t batch_total = s_total;
         const uint64_t *d = det + (uint64_t)ch * a.det_cap;
-        for (uint32_t i = 0; i < n; i++) {
-            if (excl + i < RESOLVE_LDS_HITS) s_hits[excl + i] = d[i];
-            else atomicOr(a.status, 1u);                              // more hits than one batch can hold
+        for (uint32_t win = 0; win == 0 || win < batch_total; win += HITS) {
+            if (tid == 0) { s_pend = ~0ull; s_na_out = next_allowed; }
+            for (uint32_t i = 0; i < n; i++) {
+                const uint32_t g = excl + i;
+                if (g >= win && g < win + HITS) s_hits[g - win] = d[i];
+            }
+            __syncthreads();
+            const uint32_t total = batch_total - win < (uint32_t)HITS ? batch_total - win : (uint32_t)HITS;
+            // ---- hold-off walk.  The rule is sequential (a hit is dropped iff it starts inside the hold-off of the last
+            // ACCEPTED hit), but a hit that starts at least one hold-off after the latest possible CENTRE of any earlier hit is
+            // outside every earlier burst whatever was accepted: hits are ordered by their START and a run is at most 256 phases
+            // long, so every earlier centre is below start[j-1] + 128 (the centre of hit j-1 itself is no bound: an earlier,
+            // longer run can end later -- tolerant sync lengthens runs).  Such a hit, if it also lies beyond the hold-off carried
+            // in from the previous pass / batch / push, is accepted unconditionally and heads a new chain.  Chains are walked
+            // independently, one lane each; real traffic has one hit per chain (one lane did all of it before: 125 ns per
+            // hit, 0.09 ms for the 745 bursts of one channel x 2^26).
+            for (uint32_t j = tid; j < total; j += THREADS)
+                s_head[j] = (j == 0) || ((s_hits[j] >> 8) >= (s_hits[j - 1] >> 8) + 128 + span_hold && (s_hits[j] >> 8) >= next_allowed);
+            __syncthreads();
+            for (uint32_t j = tid; j < total; j += THREADS) {
+                if (!s_head[j]) continue;
+                uint64_t na = j == 0 ? next_allowed : 0ull;           // hit 0 continues the state carried into this pass
+                uint32_t k = j;
+                do {
+                    const uint64_t ei = s_hits[k];
+                    const bool acc = (ei >> 8) >= na;
+                    if (acc) na = centre(ei) + span_hold;
+                    s_accf[k] = (uint8_t)acc;
+                    k++;
+                } while (k < total && !s_head[k]);
+                if (k == total) s_na_out = na;                        // the last chain carries the state out
+            }
+            __syncthreads();
+            for (uint32_t j = tid; j < total; j += THREADS) {
+                if (!s_accf[j]) continue;
+                const uint64_t nc = centre(s_hits[j]);
+                if (nc + span_done < a.n_proc) s_acc[atomicAdd(&s_nacc, 1u)] = nc;   // order is irrelevant: drain sorts the records
+                else s_pend = nc;                                     // tail not received yet (at most one: the last)
+            }
+            __syncthreads();
+            next_allowed = s_na_out;
+            if (s_pend != ~0ull) pend = s_pend;
+            flush();
+            if (tid == 0) s_nacc = 0;
+            __syncthreads();
         }
-        __syncthreads();
-        const uint32_t total = s_total < RESOLVE_LDS_HITS ? s_total : RESOLVE_LDS_HITS;
-        // ---- hold-off walk.  The rule is sequential (a hit is dropped iff it starts inside the hold-off of the last
-        // ACCEPTED hit), but a hit that starts at least one hold-off after the latest possible CENTRE of any earlier hit is
-        // outside every earlier burst whatever was accepted: hits are ordered by their START and a run is at most 256 phases
-        // long, so every earlier centre is below start[j-1] + 128 (the centre of hit j-1 itself is no bound: an earlier,
-        // longer run can end later -- tolerant sync lengthens runs).  Such a hit, if it also lies beyond the hold-off carried
-        // in from the previous batch / push, is accepted unconditionally and heads a new chain.  Chains are walked independently, one lane each; real traffic has one
-        // hit per chain (one lane did all of it before: 125 ns per hit, 0.09 ms for the 745 bursts of one channel x 2^26).
-        for (uint32_t j = tid; j < total; j += THREADS)
-            s_head[j] = (j == 0) || ((s_hits[j] >> 8) >= (s_hits[j - 1] >> 8) + 128 + span_hold && (s_hits[j] >> 8) >= next_allowed);
-        __syncthreads();
-        for (uint32_t j = tid; j < total; j += THREADS) {
-            if (!s_head[j]) continue;
-            uint64_t na = j == 0 ? next_allowed : 0ull;               // hit 0 continues the state carried into this batch
-            uint32_t k = j;
-            do {
-                const uint64_t ei = s_hits[k];
-                const bool acc = (ei >> 8) >= na;
-                if (acc) na = centre(ei) + span_hold;
-                s_accf[k] = (uint8_t)acc;
-                k++;
-            } while (k < total && !s_head[k]);
-            if (k == total) s_na_out = na;                            // the last chain carries the state out
-        }
-        __syncthreads();
-        for (uint32_t j = tid; j < total; j += THREADS) {
-            if (!s_accf[j]) continue;
-            const uint64_t nc = centre(s_hits[j]);
-            if (nc + span_done < a.n_proc) s_acc[atomicAdd(&s_nacc, 1u)] = nc;   // order is irrelevant: drain sorts the records
-            else s_pend = nc;                                         // tail not received yet (at most one: the last)
-        }
-        __syncthreads();
-        next_allowed = s_na_out;
-        if (s_pend != ~0ull) pend = s_pend;
-        flush();
-        if (tid == 0) s_nacc = 0;
     }
     if (nchunks == 0) flush();
     if (tid == 0) { a.next_allowed[c] = next_allowed; a.pending[c] = pend; }

@@ -476,6 +476,35 @@ def test_hold_off_chains_match_the_sequential_rule(gpu):
         assert got.tobytes() == want.tobytes()
 
 
+def test_more_trigger_hits_than_one_resolve_pass_holds(gpu):
+    """1200 truncated bursts 150 symbols apart on one channel, pushed at once: 1200 trigger hits in one batch of wave segments,
+    more than the resolve kernel's LDS window (512 hits on the narrow kernel) -- it walks them in several passes, the
+    hold-off state carried from pass to pass, and must still agree with the hit-by-hit rule of the CPU model."""
+    sps = 3
+    rng = np.random.default_rng(4242)
+    bursts, off = [], 2000
+    _, _, _, _, words = synth.random_message(rng)
+    full = synth.burst_bits(words, dcc=1, rng=rng)
+    for i in range(1200):
+        bursts.append((off, full if i % 97 == 50 else full[:60]))
+        off += (len(bursts[-1][1]) * 2 + 30) * sps if i % 97 == 50 else 150 * sps
+    N = off + 12000
+    iq = synth.fsk_modulate(N, bursts, sps=sps, fs=20e3 * sps, snr_db=30.0, rng=rng)[None, :]
+    want = oracle.fused_push_all(iq, sps=sps)
+    assert len(want) >= 12
+    for blocks in ([N], [N // 3, N // 3, N]):
+        with capi.Recc(n_channels=1, sps=sps, max_samples=N, max_bursts=256) as r:
+            o, recs = 0, []
+            for b in blocks:
+                b = min(b, N - o)
+                r.push_iq(np.ascontiguousarray(iq[:, o:o + b]))
+                recs.append(r.drain())
+                o += b
+            got = np.concatenate(recs)
+        got = got[np.lexsort((got["position"], got["channel"]))]
+        assert got.tobytes() == want.tobytes()
+
+
 @pytest.mark.parametrize("sps", [3, 4, 5, 6, 8, 10, 12])
 def test_every_supported_sample_rate_matches_the_cpu_model(gpu, sps):
     """The front kernel is instantiated per samples-per-symbol (boxcar length, correlator stride, dedup window all depend
