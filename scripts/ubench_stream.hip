@@ -54,6 +54,56 @@ __global__ __launch_bounds__(256) void k_wave(const float4 *p, size_t ld4, int t
     if (acc == 12345.f) out[0] = acc;
 }
 
+// C: the same, but the four waves of a workgroup share one stream: wave w takes tile t0 + 4 i + w at step i (16 KiB contiguous
+// per workgroup step); MODE 1 = every wave of the grid steps through the whole block together (tile i * W + g): the sweep order
+template <int DEPTH, int WORK, int MODE>
+__global__ __launch_bounds__(256) void k_wg(const float4 *p, size_t ld4, int tiles_per_chunk, int tiles_total, float *out)
+{
+    extern __shared__ float occupancy_limiter[];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (ld4 == 1) occupancy_limiter[threadIdx.x] = 0.f;
+    size_t first, stride; int n;
+    if (MODE == 0) {
+        const int c = blockIdx.y;
+        const int t0 = blockIdx.x * 4 * tiles_per_chunk;
+        if (t0 >= tiles_total) return;
+        int t1 = t0 + 4 * tiles_per_chunk; if (t1 > tiles_total) t1 = tiles_total;
+        first = (size_t)c * ld4 + (size_t)(t0 + wv) * 256; stride = 4 * 256; n = (t1 - t0 - wv + 3) / 4;
+    } else {
+        const size_t W = (size_t)gridDim.x * gridDim.y * 4, g = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv;
+        const size_t total = (size_t)gridDim.y * (ld4 / 256);            // all tiles of the block (rows are contiguous here)
+        first = g * 256; stride = W * 256; n = (int)((total - g + W - 1) / W);
+    }
+    const float4 *base = p + first + lane;
+    float4 buf[DEPTH][4];
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) buf[d][q] = base[(size_t)(d < n ? d : 0) * stride + 64 * q];
+    float acc = 0.f;
+    for (int t = 0; t < n; t++) {
+        float4 cur[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) cur[q] = buf[0][q];
+#pragma unroll
+        for (int d = 0; d + 1 < DEPTH; d++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) buf[d][q] = buf[d + 1][q];
+        if (t + DEPTH < n) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) buf[DEPTH - 1][q] = base[(size_t)(t + DEPTH) * stride + 64 * q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            float x = cur[q].x, y = cur[q].y, z = cur[q].z, w = cur[q].w;
+#pragma unroll
+            for (int r = 0; r < WORK; r++) { x = __builtin_fmaf(x, y, z); y = __builtin_fmaf(y, z, w); z = __builtin_fmaf(z, w, x); w = __builtin_fmaf(w, x, y); }
+            acc += x + y + z + w;
+        }
+    }
+    if (acc == 12345.f) out[0] = acc;
+}
+
 template <typename F> float time_ms(F f, int reps = 10)
 {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -71,7 +121,26 @@ int main()
     printf("bytes per pass %.3f GB\n", bytes / 1e9);
     float ms = time_ms([&] { hipLaunchKernelGGL(k_linear, dim3(256 * 8), dim3(256), 0, 0, d, bytes / 16, out); });
     printf("A linear float4 read            : %.3f ms  %.0f GB/s\n", ms, bytes / ms / 1e6);
-    for (int wgs_per_cu : { 8, 6, 5, 4, 3, 2 }) {      // 4 waves per workgroup
+    for (int wgs_per_cu : { 8, 5, 4, 3 }) {
+        const int tpc = 52;
+        int nch = (tiles_total + 4 * tpc - 1) / (4 * tpc);
+        dim3 g(nch, C);
+        size_t lds = 160 * 1024 / wgs_per_cu - 512;
+        hipFuncSetAttribute((const void *)k_wg<1, 20, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void *)k_wg<2, 20, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void *)k_wg<1, 20, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void *)k_wg<2, 20, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        ms = time_ms([&] { hipLaunchKernelGGL((k_wg<1, 20, 0>), g, dim3(256), lds, 0, d, ld4, tpc, tiles_total, out); });
+        printf("WG-stream waves/CU %2d depth1 : %.3f ms  %.0f GB/s\n", wgs_per_cu * 4, ms, bytes / ms / 1e6);
+        ms = time_ms([&] { hipLaunchKernelGGL((k_wg<2, 20, 0>), g, dim3(256), lds, 0, d, ld4, tpc, tiles_total, out); });
+        printf("WG-stream waves/CU %2d depth2 : %.3f ms  %.0f GB/s\n", wgs_per_cu * 4, ms, bytes / ms / 1e6);
+        dim3 gs(256 * wgs_per_cu, 1);          // one resident round; MODE 1 needs total tiles: pass ld4 * C as one row
+        ms = time_ms([&] { hipLaunchKernelGGL((k_wg<1, 20, 1>), gs, dim3(256), lds, 0, d, ld4 * C, tpc, tiles_total, out); });
+        printf("sweep     waves/CU %2d depth1 : %.3f ms  %.0f GB/s\n", wgs_per_cu * 4, ms, bytes / ms / 1e6);
+        ms = time_ms([&] { hipLaunchKernelGGL((k_wg<2, 20, 1>), gs, dim3(256), lds, 0, d, ld4 * C, tpc, tiles_total, out); });
+        printf("sweep     waves/CU %2d depth2 : %.3f ms  %.0f GB/s\n", wgs_per_cu * 4, ms, bytes / ms / 1e6);
+    }
+    for (int wgs_per_cu : { 8, 5, 4, 3 }) {      // 4 waves per workgroup
         const int tpc = 52;
         int nch = (tiles_total + tpc - 1) / tpc;
         dim3 g((nch + 3) / 4, C);
