@@ -149,12 +149,15 @@ struct SpanGuard {   // records a pair of events around a launch when timing is 
         if (!a || !b) { on = false; return; }
         (void)hipEventRecord(a, h->stream);
     }
-    ~SpanGuard()
+    void end()     // close the span now (the destructor then does nothing)
     {
         if (!on) return;
         (void)hipEventRecord(b, h->stream);
         h->spans.push_back({ a, b, tag, samples });
+        on = false;
     }
+    static void end_cb(void *g) { static_cast<SpanGuard *>(g)->end(); }
+    ~SpanGuard() { end(); }
 };
 
 void collect_spans(amps_recc *h)   // collects the spans whose events have completed (all of them after a stream sync)
@@ -760,7 +763,8 @@ int amps_recc_push_wideband(amps_recc_t *h, const float *iq, size_t nsamp, int m
     int rc;
     {
         SpanGuard g(h, T_CHANNELIZER, nsamp);
-        rc = channelizer_run(h->chz, (const float2 *)iq, nsamp, mem, h->stream, &chan_iq, &ld, &nout, fused, h->gring, h->ring_words, h->n_done, h->slicer);
+        rc = channelizer_run(h->chz, (const float2 *)iq, nsamp, mem, h->stream, &chan_iq, &ld, &nout, fused, h->gring, h->ring_words, h->n_done, h->slicer,
+                             SpanGuard::end_cb, &g);
     }
     if (rc) return rc;
     if (nout > h->cfg.max_samples_per_push) return -E2BIG;

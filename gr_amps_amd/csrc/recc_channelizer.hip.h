@@ -1148,7 +1148,7 @@ inline int channelizer_create(ChannelizerState &z, const amps_recc_cfg_t &cfg, h
 inline int channelizer_run(ChannelizerState &z, const float2 *iq, size_t nsamp, int mem, hipStream_t s,
                            const float2 **chan_iq, uint64_t *ld, uint32_t *nframes_out,
                            bool fused = false, uint64_t *gring = nullptr, uint32_t ring_words = 0, uint64_t n_done = 0,
-                           int slicer = AMPS_SLICER_ATAN_BOXCAR)
+                           int slicer = AMPS_SLICER_ATAN_BOXCAR, void (*after_main)(void *) = nullptr, void *after_ctx = nullptr)
 {
     if (!z.enabled) return -ENOSYS;
     const float2 *d = iq;
@@ -1210,6 +1210,7 @@ inline int channelizer_run(ChannelizerState &z, const float2 *iq, size_t nsamp, 
             else hipLaunchKernelGGL(chz_pfb_fft_kernel<16>, dim3(nwg), dim3(256), 0, s, a);
         }
     }
+    if (after_main) after_main(after_ctx);                            // timing: the span ends behind the filter-bank kernel, before the carry copy
     const uint32_t consumed = nframes * CHZ_D;                        // virtual samples consumed (incl. leftover)
     const uint32_t new_left = (uint32_t)(avail - consumed);
     hipLaunchKernelGGL(chz_carry_kernel, dim3((hist + new_left + 255) / 256), dim3(256), 0, s, d, z.carry[z.carry_cur],

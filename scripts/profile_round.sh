@@ -6,7 +6,7 @@ OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-other-specs --slicer $SL"          # wideband832 + secondary direct832
+BENCH="python $R/bench.py --no-cpu-baseline --no-other-specs --slicer $SL"          # the default command (12000 steps of wideband832 + 2000 of direct832) without its CPU legs
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
 SHORT="python $R/bench.py --steps 4 --warmup 2 --prewarm-ms 50 --no-cpu-baseline --no-other-specs --slicer $SL"
 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmc1 -o pmc -- $SHORT > $OUT/pmc1.log 2>&1
