@@ -14,6 +14,7 @@
 #include "amps_recc.h"
 #include "amps_recc_numerics.h"
 #include "recc_front.hip.h"
+#include "recc_front_coop.hip.h"
 #include "recc_resolve.hip.h"
 #include "recc_symbols.hip.h"
 #include "recc_channelizer.hip.h"
@@ -61,6 +62,7 @@ struct amps_recc {
     uint64_t *gring = nullptr;
     uint32_t ring_words = 0;
     uint32_t max_waves = 0, max_chunks = 0, det_cap = 0;   // front-launch geometry bounds (see run_iq_device)
+    uint32_t coop_w = 0, max_wgs_coop = 0;                 // cooperative front kernel: waves per workgroup (0 = not used), resident workgroups
     uint32_t max_waves_bits = 0;                           // the same for the bit-domain kernel (more waves fit: 72 VGPRs, 2 KB LDS)
     uint64_t *det = nullptr;
     uint32_t *detcount = nullptr;
@@ -309,6 +311,55 @@ template <int SPS> void launch_front(const FrontArgs &fa, dim3 grid, hipStream_t
     }
 }
 
+// cooperative form (recc_front_coop.hip.h): the 4 waves of a workgroup on 4 consecutive tiles.  Opt-in (AMPS_RECC_COOP=4):
+// measured equal to the wave-private kernel within the run-to-run spread for spec C, slower for spec A
+constexpr int COOP_W = 4;
+template <int SPS> int coop_blocks_per_cu_t(int slicer)
+{
+    int n = 0;
+    hipError_t e = slicer == AMPS_SLICER_SINE
+        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, recc_front_coop_kernel<SPS, COOP_W, AMPS_SLICER_SINE>, 64 * COOP_W, 0)
+        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, recc_front_coop_kernel<SPS, COOP_W, AMPS_SLICER_ATAN_BOXCAR>, 64 * COOP_W, 0);
+    return (e == hipSuccess && n > 0) ? n : 1;
+}
+template <int SPS> void launch_coop_t(const FrontArgs &fa, dim3 grid, hipStream_t s, int slicer)
+{
+    if (slicer == AMPS_SLICER_SINE) hipLaunchKernelGGL((recc_front_coop_kernel<SPS, COOP_W, AMPS_SLICER_SINE>), grid, dim3(64 * COOP_W), 0, s, fa);
+    else hipLaunchKernelGGL((recc_front_coop_kernel<SPS, COOP_W, AMPS_SLICER_ATAN_BOXCAR>), grid, dim3(64 * COOP_W), 0, s, fa);
+}
+int coop_blocks_per_cu(uint32_t sps, int slicer)
+{
+    switch (sps) {
+    case 3: return coop_blocks_per_cu_t<3>(slicer);
+    case 4: return coop_blocks_per_cu_t<4>(slicer);
+    case 5: return coop_blocks_per_cu_t<5>(slicer);
+    case 6: return coop_blocks_per_cu_t<6>(slicer);
+    case 8: return coop_blocks_per_cu_t<8>(slicer);
+    case 10: return coop_blocks_per_cu_t<10>(slicer);
+    case 12: return coop_blocks_per_cu_t<12>(slicer);
+    default: return 0;
+    }
+}
+int dispatch_coop(uint32_t sps, const FrontArgs &fa, dim3 grid, hipStream_t s, int slicer)
+{
+    switch (sps) {
+    case 3: launch_coop_t<3>(fa, grid, s, slicer); break;
+    case 4: launch_coop_t<4>(fa, grid, s, slicer); break;
+    case 5: launch_coop_t<5>(fa, grid, s, slicer); break;
+    case 6: launch_coop_t<6>(fa, grid, s, slicer); break;
+    case 8: launch_coop_t<8>(fa, grid, s, slicer); break;
+    case 10: launch_coop_t<10>(fa, grid, s, slicer); break;
+    case 12: launch_coop_t<12>(fa, grid, s, slicer); break;
+    default: return -EINVAL;
+    }
+    return 0;
+}
+bool coop_wanted()   // read at every create
+{
+    const char *e = std::getenv("AMPS_RECC_COOP");
+    return e && std::atoi(e) == COOP_W;
+}
+
 bool sps_supported(uint32_t sps)
 {
     switch (sps) { case 3: case 4: case 5: case 6: case 8: case 10: case 12: return true; default: return false; }
@@ -349,7 +400,10 @@ int run_iq_device(amps_recc *h, const float2 *iq, uint64_t ld, uint32_t nsamp)
     // geometry of the persistent front launch
     const uint32_t Tc = (P + TILE - 1) / TILE;
     const uint64_t G = (uint64_t)h->C * Tc;
-    uint32_t nwaves = (uint32_t)std::min<uint64_t>(h->max_waves, (G + MIN_SPAN - 1) / MIN_SPAN);
+    // segment owners: waves (recc_front_kernel) or workgroups of coop_w waves (recc_front_coop_kernel; not with the debug taps)
+    const uint32_t coop = (h->coop_w && !h->dbg_d) ? h->coop_w : 0u;
+    const uint64_t min_span = coop ? MIN_SPAN * coop : MIN_SPAN;
+    uint32_t nwaves = (uint32_t)std::min<uint64_t>(coop ? h->max_wgs_coop : h->max_waves, (G + min_span - 1) / min_span);
     if (nwaves == 0) nwaves = 1;
     const uint32_t span = (uint32_t)((G + nwaves - 1) / nwaves);
     if (P && (uint64_t)(Tc + span - 1) / span + 1 > h->max_chunks) return -E2BIG;
@@ -366,7 +420,8 @@ int run_iq_device(amps_recc *h, const float2 *iq, uint64_t ld, uint32_t nsamp)
         if (debug_sync_enabled())
             std::fprintf(stderr, "amps_recc[debug]: front waves=%u span=%u Tc=%u C=%u P=%u avail=%u r_prev=%u ld=%llu n_done=%llu ring_words=%u max_chunks=%u det_cap=%u\n",
                          nwaves, span, Tc, h->C, P, avail, h->r_prev, (unsigned long long)ld, (unsigned long long)h->n_done, h->ring_words, h->max_chunks, h->det_cap);
-        int rc = dispatch_front(h->sps, fa, dim3((nwaves + 3) / 4), s, h->slicer);
+        int rc = coop ? dispatch_coop(h->sps, fa, dim3(nwaves), s, h->slicer)
+                      : dispatch_front(h->sps, fa, dim3((nwaves + 3) / 4), s, h->slicer);
         if (rc) return rc;
     }
     if (int rc = debug_sync(h, "front")) return rc;
@@ -517,7 +572,12 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
             h->max_waves_bits = (uint32_t)prop.multiProcessorCount * 4u * (uint32_t)nb;
         }
         const uint64_t max_tiles = (maxs + 63 + TILE - 1) / TILE;
-        const uint64_t max_span = std::max<uint64_t>(MIN_SPAN, (C * max_tiles + h->max_waves - 1) / h->max_waves);
+        uint64_t max_span = std::max<uint64_t>(MIN_SPAN, (C * max_tiles + h->max_waves - 1) / h->max_waves);
+        if (cfg->sync_tolerance == 0 && h->slicer != AMPS_SLICER_PRODUCT && coop_wanted()) {
+            h->coop_w = COOP_W;
+            h->max_wgs_coop = (uint32_t)prop.multiProcessorCount * (uint32_t)coop_blocks_per_cu(h->sps, h->slicer);
+            max_span = std::max<uint64_t>(max_span, std::max<uint64_t>(MIN_SPAN * h->coop_w, (C * max_tiles + h->max_wgs_coop - 1) / h->max_wgs_coop));
+        }
         h->max_chunks = (uint32_t)(prop.multiProcessorCount * 32u / C + 3);   // bound for any occupancy
         h->det_cap = (uint32_t)(max_span * TILE / ((uint64_t)AMPS_RECC_TRIGGER_SYMS * h->sps) + 4);
         rc |= dev_alloc(&h->carry[0], C * CARRY_CAP);

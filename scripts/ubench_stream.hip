@@ -56,8 +56,8 @@ __global__ __launch_bounds__(256) void k_wave(const float4 *p, size_t ld4, int t
 
 // C: the same, but the four waves of a workgroup share one stream: wave w takes tile t0 + 4 i + w at step i (16 KiB contiguous
 // per workgroup step); MODE 1 = every wave of the grid steps through the whole block together (tile i * W + g): the sweep order
-template <int DEPTH, int WORK, int MODE>
-__global__ __launch_bounds__(256) void k_wg(const float4 *p, size_t ld4, int tiles_per_chunk, int tiles_total, float *out)
+template <int DEPTH, int WORK, int MODE, int NW = 4, bool BAR = false>
+__global__ __launch_bounds__(64 * NW) void k_wg(const float4 *p, size_t ld4, int tiles_per_chunk, int tiles_total, float *out)
 {
     extern __shared__ float occupancy_limiter[];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -65,10 +65,11 @@ __global__ __launch_bounds__(256) void k_wg(const float4 *p, size_t ld4, int til
     size_t first, stride; int n;
     if (MODE == 0) {
         const int c = blockIdx.y;
-        const int t0 = blockIdx.x * 4 * tiles_per_chunk;
+        const int t0 = blockIdx.x * NW * tiles_per_chunk;
         if (t0 >= tiles_total) return;
-        int t1 = t0 + 4 * tiles_per_chunk; if (t1 > tiles_total) t1 = tiles_total;
-        first = (size_t)c * ld4 + (size_t)(t0 + wv) * 256; stride = 4 * 256; n = (t1 - t0 - wv + 3) / 4;
+        int t1 = t0 + NW * tiles_per_chunk; if (t1 > tiles_total) t1 = tiles_total;
+        first = (size_t)c * ld4 + (size_t)(t0 + wv) * 256; stride = NW * 256; n = (t1 - t0 - wv + NW - 1) / NW;
+        if (BAR) n = (t1 - t0) / NW;                                     // uniform step count (tiles_total is a multiple here)
     } else {
         const size_t W = (size_t)gridDim.x * gridDim.y * 4, g = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv;
         const size_t total = (size_t)gridDim.y * (ld4 / 256);            // all tiles of the block (rows are contiguous here)
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(256) void k_wg(const float4 *p, size_t ld4, int til
             for (int r = 0; r < WORK; r++) { x = __builtin_fmaf(x, y, z); y = __builtin_fmaf(y, z, w); z = __builtin_fmaf(z, w, x); w = __builtin_fmaf(w, x, y); }
             acc += x + y + z + w;
         }
+        if (BAR) { occupancy_limiter[threadIdx.x] = acc; __syncthreads(); acc += occupancy_limiter[(threadIdx.x + 64) % (64 * NW)]; }
     }
     if (acc == 12345.f) out[0] = acc;
 }
@@ -121,7 +123,25 @@ int main()
     printf("bytes per pass %.3f GB\n", bytes / 1e9);
     float ms = time_ms([&] { hipLaunchKernelGGL(k_linear, dim3(256 * 8), dim3(256), 0, 0, d, bytes / 16, out); });
     printf("A linear float4 read            : %.3f ms  %.0f GB/s\n", ms, bytes / ms / 1e6);
-    for (int wgs_per_cu : { 8, 5, 4, 3 }) {
+    {
+        // workgroup-stream with a barrier per step (the cooperative front-kernel shape): NW waves, waves/CU held at 16 and 12
+        auto run = [&](auto kern, int nw, int waves_per_cu, int tpc, const char *name) {
+            int nch = (tiles_total + nw * tpc - 1) / (nw * tpc);
+            dim3 g(nch, C);
+            size_t lds = 160 * 1024 / (waves_per_cu / nw) - 512; if (lds > 64 * 1024) lds = 64 * 1024;
+            hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            float t = time_ms([&] { hipLaunchKernelGGL(kern, g, dim3(64 * nw), lds, 0, d, ld4, tpc, tiles_total, out); });
+            printf("%s NW %2d waves/CU %2d tpc %3d : %.3f ms  %.0f GB/s\n", name, nw, waves_per_cu, tpc, t, bytes / t / 1e6);
+        };
+        for (int wpc : { 16, 12 }) {
+            run(k_wg<1, 20, 0, 4, true>, 4, wpc, 64, "coop+barrier");
+            run(k_wg<1, 20, 0, 8, true>, 8, wpc == 12 ? 16 : wpc, 32, "coop+barrier");
+            run(k_wg<1, 20, 0, 16, true>, 16, 16, 16, "coop+barrier");
+            run(k_wg<1, 20, 0, 4, false>, 4, wpc, 64, "coop        ");
+            run(k_wg<1, 20, 0, 16, false>, 16, 16, 16, "coop        ");
+        }
+    }
+    for (int wgs_per_cu : { 8, 4 }) {
         const int tpc = 52;
         int nch = (tiles_total + 4 * tpc - 1) / (4 * tpc);
         dim3 g(nch, C);
@@ -140,7 +160,7 @@ int main()
         ms = time_ms([&] { hipLaunchKernelGGL((k_wg<2, 20, 1>), gs, dim3(256), lds, 0, d, ld4 * C, tpc, tiles_total, out); });
         printf("sweep     waves/CU %2d depth2 : %.3f ms  %.0f GB/s\n", wgs_per_cu * 4, ms, bytes / ms / 1e6);
     }
-    for (int wgs_per_cu : { 8, 5, 4, 3 }) {      // 4 waves per workgroup
+    for (int wgs_per_cu : { 4, 3 }) {      // 4 waves per workgroup
         const int tpc = 52;
         int nch = (tiles_total + tpc - 1) / tpc;
         dim3 g((nch + 3) / 4, C);

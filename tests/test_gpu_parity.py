@@ -476,6 +476,43 @@ def test_hold_off_chains_match_the_sequential_rule(gpu):
         assert got.tobytes() == want.tobytes()
 
 
+@pytest.mark.parametrize("sps,slicer", [(3, "sine"), (10, "sine"), (12, "sine"), (5, "atan"), (10, "atan")])
+def test_cooperative_front_kernel_matches_the_cpu_model(gpu, monkeypatch, sps, slicer):
+    """AMPS_RECC_COOP=4 selects recc_front_coop_kernel (four waves of a workgroup on four consecutive tiles, shared LDS bit
+    ring, deferred run-start pass): same records as the CPU model, byte for byte, on ragged pushes that cut bursts, with
+    several channels per workgroup span and with spans that cross channel boundaries."""
+    monkeypatch.setenv("AMPS_RECC_COOP", "4")
+    C = 5
+    N = 3 * 3600 * 2 * sps + 7000
+    rng = np.random.default_rng(900 + sps)
+    specs = []
+    for c in range(C):
+        off, bursts = int(rng.integers(300, 4000)), []
+        for _ in range(3):
+            _, _, _, _, words = synth.random_message(rng)
+            bits = synth.burst_bits(words, dcc=int(rng.integers(0, 4)), rng=rng)
+            bursts.append((off, bits))
+            off += int(len(bits) * 2 * sps + rng.integers(100, 1500) * sps)
+        specs.append(bursts)
+    iq = np.stack([synth.fsk_modulate(N, b, sps=sps, fs=20e3 * sps, snr_db=14.0 if c == 1 else 30.0, rng=rng) for c, b in enumerate(specs)])
+    code = {"atan": 0, "sine": 2}[slicer]
+    want = oracle.fused_push_all(iq, sps=sps, slicer=code)
+    assert len(want) >= 10
+    for blocks in ([N], [64, 4000, 1, N // 2, 777, N]):
+        with capi.Recc(n_channels=C, sps=sps, max_samples=N, max_bursts=256, slicer=slicer) as r:
+            o, recs = 0, []
+            for b in blocks:
+                b = min(b, N - o)
+                if b <= 0:
+                    break
+                r.push_iq(np.ascontiguousarray(iq[:, o:o + b]))
+                recs.append(r.drain())
+                o += b
+            got = np.concatenate(recs)
+        got = got[np.lexsort((got["position"], got["channel"]))]
+        assert got.tobytes() == want.tobytes()
+
+
 def test_more_trigger_hits_than_one_resolve_pass_holds(gpu):
     """1200 truncated bursts 150 symbols apart on one channel, pushed at once: 1200 trigger hits in one batch of wave segments,
     more than the resolve kernel's LDS window (512 hits on the narrow kernel) -- it walks them in several passes, the
