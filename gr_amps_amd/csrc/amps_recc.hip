@@ -73,7 +73,8 @@ struct amps_recc {
     uint32_t *nrecords = nullptr;
     uint32_t *status = nullptr;
     amps_recc_burst_t *rec_host = nullptr;   // mapped pinned host memory: the capture kernel writes records here directly
-    uint32_t *hdr_host = nullptr;             // pinned {nrecords, status} per record list
+    uint32_t *hdr_host = nullptr, *hdr_dev = nullptr;   // mapped pinned {nrecords, status} per record list: written by the capture kernel's last workgroup
+    bool list_clean[2] = { true, true };      // the device-side {nrecords, status} of the list are zero (or a launch that zeroes them is enqueued)
     // two record lists: pushes append to the current one; drain_begin closes it (and switches), drain_end collects it
     amps_recc_burst_t *rec_host_buf[2] = { nullptr, nullptr }, *records_buf[2] = { nullptr, nullptr };
     uint8_t *bsym_host_buf[2] = { nullptr, nullptr }, *bsym_dev_buf[2] = { nullptr, nullptr };   // AMPS_RECC_FLAG_KEEP_BURSTS: [max_bursts][3374], mapped pinned
@@ -202,6 +203,7 @@ void select_record_list(amps_recc *h, int b)
     h->nrecords = h->nrecords_buf[b]; h->status = h->status_buf[b];
 }
 
+constexpr int HDR_STRIDE = 16;      // dwords between the two lists' host headers (one 64-byte line each: the CPU clears one while the GPU may write the other)
 constexpr uint64_t MIN_SPAN = 16;   // tiles per wave at least: bounds the 2-tile halo overhead to 12.5 % on tiny pushes
 
 uint32_t next_pow2(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return (uint32_t)p; }
@@ -216,11 +218,13 @@ int reset_state(amps_recc *h)
         HIP_TRY(hipMemsetAsync(h->detcount, 0, sizeof(uint32_t) * (size_t)h->C * h->max_chunks, s));
         HIP_TRY(hipMemsetAsync(h->next_allowed, 0, sizeof(uint64_t) * h->C, s));
         HIP_TRY(hipMemsetAsync(h->pending, 0xff, sizeof(uint64_t) * h->C, s));
-        HIP_TRY(hipMemsetAsync(h->capq_count, 0, sizeof(uint32_t), s));
+        HIP_TRY(hipMemsetAsync(h->capq_count, 0, 2 * sizeof(uint32_t), s));   // {queue count, finished capture workgroups}
     }
     for (int b = 0; b < 2; b++) {
         HIP_TRY(hipMemsetAsync(h->nrecords_buf[b], 0, 2 * sizeof(uint32_t), s));
+        h->list_clean[b] = true;
     }
+    std::memset(h->hdr_host, 0, 2 * HDR_STRIDE * sizeof(uint32_t));
     h->open_buf = -1;
     select_record_list(h, 0);
     HIP_TRY(hipMemsetAsync(h->symbuf, 0, (size_t)h->C * AMPS_RECC_SYMBUF, s));
@@ -380,6 +384,19 @@ int dispatch_front(uint32_t sps, const FrontArgs &fa, dim3 grid, hipStream_t s, 
     return 0;
 }
 
+// The streaming / bit-domain kernel of a push also does the push's housekeeping (thread 0): it clears the capture queue count,
+// and the {count, status} of the record list that is NOT current if those are still dirty from its last use -- a list is only
+// appended to while it is current, and a drain reads its header from host memory (published by the capture kernel), so the
+// idle list's device counters are free to be cleared by any later launch.  Two memsets and one copy fewer per push.
+void front_housekeeping_args(amps_recc *h, FrontArgs &fa)
+{
+    fa.zero1 = h->capq_count;
+    const int idle = h->cur_buf ^ 1;
+    fa.zero2 = h->list_clean[idle] ? nullptr : h->nrecords_buf[idle];
+    h->list_clean[idle] = true;
+    h->list_clean[h->cur_buf] = false;      // the capture kernel of this push may append to the current list
+}
+
 // the fused chain on channel-major device IQ: front -> carry -> resolve -> capture/decode
 // one workgroup per channel; wide groups when a channel spans more wave segments than 256 lanes cover in one batch
 static void launch_resolve(amps_recc *h, const ResolveArgs &ra, hipStream_t s)
@@ -416,6 +433,7 @@ int run_iq_device(amps_recc *h, const float2 *iq, uint64_t ld, uint32_t nsamp)
         fa.tol = h->cfg.sync_tolerance;
         fa.force_ones = (h->slicer == AMPS_SLICER_PRODUCT && h->n_done == h->origin) ? h->sps : 0u;   // spec B: no partner yet
         fa.status = h->status; fa.dbg_d = h->dbg_d; fa.dbg_S = h->dbg_S; fa.dbg_channel = 0;
+        front_housekeeping_args(h, fa);
         SpanGuard g(h, T_FRONT, P);
         if (debug_sync_enabled())
             std::fprintf(stderr, "amps_recc[debug]: front waves=%u span=%u Tc=%u C=%u P=%u avail=%u r_prev=%u ld=%llu n_done=%llu ring_words=%u max_chunks=%u det_cap=%u\n",
@@ -434,7 +452,6 @@ int run_iq_device(amps_recc *h, const float2 *iq, uint64_t ld, uint32_t nsamp)
     }
     if (int rc = debug_sync(h, "carry")) return rc;
     if (P) {
-        HIP_TRY(hipMemsetAsync(h->capq_count, 0, sizeof(uint32_t), s));
         ResolveArgs ra{};
         ra.det = h->det; ra.detcount = h->detcount; ra.max_chunks = h->max_chunks; ra.det_cap = h->det_cap;
         ra.tiles_per_channel = Tc; ra.span = span; ra.sps = h->sps; ra.n_proc = h->n_done + P;
@@ -451,6 +468,7 @@ int run_iq_device(amps_recc *h, const float2 *iq, uint64_t ld, uint32_t nsamp)
         ca.records = h->records; ca.nrecords = h->nrecords; ca.rec_cap = h->cfg.max_bursts; ca.status = h->status;
         ca.majority = (h->cfg.flags & AMPS_RECC_FLAG_MAJORITY) ? 1u : 0u;
         ca.burst_syms = h->bsym_dev_buf[h->cur_buf];
+        ca.done_blocks = h->capq_count + 1; ca.hdr_host = h->hdr_dev + HDR_STRIDE * h->cur_buf;
         {
             SpanGuard g(h, T_DECODE);
             uint32_t grid = std::min<uint32_t>(h->cfg.max_bursts, 2048u);
@@ -546,7 +564,8 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
         for (int b = 0; b < 2; b++)
             if (hipHostMalloc((void **)&h->bsym_host_buf[b], (size_t)cfg->max_bursts * AMPS_RECC_CAPTURE_SYMS, hipHostMallocMapped) != hipSuccess ||
                 hipHostGetDevicePointer((void **)&h->bsym_dev_buf[b], h->bsym_host_buf[b], 0) != hipSuccess) rc |= -ENOMEM;
-    if (hipHostMalloc((void **)&h->hdr_host, 4 * sizeof(uint32_t)) != hipSuccess) rc |= -ENOMEM;
+    if (hipHostMalloc((void **)&h->hdr_host, 2 * HDR_STRIDE * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&h->hdr_dev, h->hdr_host, 0) != hipSuccess) rc |= -ENOMEM;
     if (hipEventCreateWithFlags(&h->drain_event, hipEventDisableTiming) != hipSuccess) rc |= -ENOMEM;
     if (!rc) select_record_list(h, 0);
     // IQ seam
@@ -588,7 +607,7 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
         rc |= dev_alloc(&h->next_allowed, C);
         rc |= dev_alloc(&h->pending, C);
         rc |= dev_alloc(&h->capq, cfg->max_bursts);
-        rc |= dev_alloc(&h->capq_count, 1);
+        rc |= dev_alloc(&h->capq_count, 2);     // {queue count, finished capture workgroups}
     }
     if (!rc && cfg->wideband_channels) rc = channelizer_create(h->chz, *cfg, h->stream);
     if (!rc) rc = reset_state(h);
@@ -769,6 +788,7 @@ int run_bits_device(amps_recc *h, uint32_t P)
     fa.n_done = h->n_done; fa.gring = h->gring; fa.ring_mask = h->ring_words - 1; fa.ring_words = h->ring_words;
     fa.det = h->det; fa.detcount = h->detcount; fa.max_chunks = h->max_chunks; fa.det_cap = h->det_cap; fa.status = h->status;
     fa.tol = h->cfg.sync_tolerance;
+    front_housekeeping_args(h, fa);
     {
         SpanGuard g(h, T_FRONT, P);
         // the dedicated bit-domain kernel; AMPS_RECC_BITS_KERNEL=front selects the bit-domain mode of the streaming kernel
@@ -780,7 +800,6 @@ int run_bits_device(amps_recc *h, uint32_t P)
         } else if (fa.tol) hipLaunchKernelGGL((recc_bits_kernel<3, true>), grid, dim3(256), 0, s, fa);
         else hipLaunchKernelGGL((recc_bits_kernel<3, false>), grid, dim3(256), 0, s, fa);
     }
-    HIP_TRY(hipMemsetAsync(h->capq_count, 0, sizeof(uint32_t), s));
     ResolveArgs ra{};
     ra.det = h->det; ra.detcount = h->detcount; ra.max_chunks = h->max_chunks; ra.det_cap = h->det_cap;
     ra.tiles_per_channel = Tc; ra.span = span; ra.sps = h->sps; ra.n_proc = h->n_done + P;
@@ -796,6 +815,7 @@ int run_bits_device(amps_recc *h, uint32_t P)
     ca.records = h->records; ca.nrecords = h->nrecords; ca.rec_cap = h->cfg.max_bursts; ca.status = h->status;
     ca.majority = (h->cfg.flags & AMPS_RECC_FLAG_MAJORITY) ? 1u : 0u;
     ca.burst_syms = h->bsym_dev_buf[h->cur_buf];
+    ca.done_blocks = h->capq_count + 1; ca.hdr_host = h->hdr_dev + HDR_STRIDE * h->cur_buf;
     {
         SpanGuard g(h, T_DECODE);
         hipLaunchKernelGGL(recc_capture_kernel, dim3(std::min<uint32_t>(h->cfg.max_bursts, 2048u)), dim3(64), 0, s, ca);
@@ -952,11 +972,14 @@ int amps_recc_drain_begin(amps_recc_t *h)
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = h->stream;
     const int b = h->cur_buf;
-    uint32_t *hdr = h->hdr_host + 2 * b;
-    HIP_TRY(hipMemcpyAsync(&hdr[0], h->nrecords_buf[b], 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    // the list's header is already on its way to host memory: the last capture workgroup of every push writes it
     HIP_TRY(hipEventRecord(h->drain_event, s));
     h->open_buf = b;
     select_record_list(h, b ^ 1);           // later pushes append to the other list
+    if (!h->list_clean[b ^ 1]) {            // drained twice with no push in between: nobody has cleared it yet
+        HIP_TRY(hipMemsetAsync(h->nrecords_buf[b ^ 1], 0, 2 * sizeof(uint32_t), s));
+        h->list_clean[b ^ 1] = true;
+    }
     return 0;
 }
 
@@ -980,15 +1003,16 @@ static int drain_end_impl(amps_recc_t *h, amps_recc_burst_t *out, uint8_t *burst
     *nout = 0;
     if (h->open_buf < 0) return -EINVAL;
     HIP_TRY(hipSetDevice(h->device));
-    hipStream_t s = h->stream;
     const int b = h->open_buf;
     HIP_TRY(hipEventSynchronize(h->drain_event));   // everything enqueued before drain_begin is done; later pushes may still run
     collect_spans(h);
-    const uint32_t *hdr = h->hdr_host + 2 * b;
+    volatile uint32_t *hdr = h->hdr_host + HDR_STRIDE * b;
     uint32_t n = hdr[0];
+    const uint32_t st = hdr[1];
+    hdr[0] = 0u; hdr[1] = 0u;               // empty until a capture kernel publishes into it again (the list is not current now)
     int rc = 0;
-    if (hdr[1] & 1u) rc = -EOVERFLOW;
-    if ((hdr[1] & (2u | 4u)) || n > h->cfg.max_bursts) { rc = -ENOSPC; }
+    if (st & 1u) rc = -EOVERFLOW;
+    if ((st & (2u | 4u)) || n > h->cfg.max_bursts) { rc = -ENOSPC; }
     if (n > h->cfg.max_bursts) n = h->cfg.max_bursts;
     if (n) {
         // the records are already in host memory (written by the capture kernel, visible after the event above);
@@ -1006,8 +1030,7 @@ static int drain_end_impl(amps_recc_t *h, amps_recc_burst_t *out, uint8_t *burst
         *nout = k;
         if (n > cap) rc = -ENOSPC;
     }
-    // the list is empty again before it becomes current (stream order: these precede every later push into it)
-    HIP_TRY(hipMemsetAsync(h->nrecords_buf[b], 0, 2 * sizeof(uint32_t), s));
+    // the list's device counters are cleared by the next push (front_housekeeping_args) or by the next drain_begin
     h->open_buf = -1;
     return rc;
 }

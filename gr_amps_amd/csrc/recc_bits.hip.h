@@ -25,6 +25,7 @@ __global__ __launch_bounds__(256) void recc_bits_kernel(FrontArgs a)
     constexpr int K = (HIST + 31) / 32;                  // history dwords a lane needs besides its own
     static_assert(D <= 32 && K <= 10, "bit-domain kernel is for small samples-per-symbol");
     __shared__ uint32_t s_w_all[4][K + 64];
+    front_housekeeping(a);
 
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;

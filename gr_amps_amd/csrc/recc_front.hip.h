@@ -89,7 +89,16 @@ struct FrontArgs {
     uint32_t dbg_channel;
     uint32_t tol;            // TOL kernels: accepted mismatching trigger symbols (cfg.sync_tolerance)
     uint32_t force_ones;     // spec B: rel samples [0, force_ones) have no partner yet (stream start): g = 1
+    uint32_t *zero1;         // housekeeping done by thread 0 of the launch instead of separate memsets on the stream: one dword to
+    uint32_t *zero2;         // clear (the capture queue count) and an optional pair (the idle record list's {count, status})
 };
+__device__ __forceinline__ void front_housekeeping(const FrontArgs &a)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (a.zero1) *a.zero1 = 0u;
+        if (a.zero2) { a.zero2[0] = 0u; a.zero2[1] = 0u; }
+    }
+}
 
 typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));  // two fc32 samples, 8-byte aligned
 
@@ -249,6 +258,7 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc
 {
     constexpr bool PROD = SL == AMPS_SLICER_PRODUCT;
     static_assert(!PROD || (!BITS && SPS <= XHIST), "spec B runs on IQ");
+    front_housekeeping(a);
     static_assert(SPS >= 2 && SPS <= 16, "samples per symbol");
     constexpr int H = SPS - 1;                  // boxcar history
     constexpr int D = AMPS_DEDUP_SYMBOLS * SPS; // dedup / run window in samples (<= 32)

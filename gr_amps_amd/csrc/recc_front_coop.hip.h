@@ -43,6 +43,7 @@ __global__ __launch_bounds__(64 * W, 4) void recc_front_coop_kernel(FrontArgs a)
     __shared__ uint32_t s_g[RW32 + 2];          // slicer bits; [RW32], [RW32 + 1] mirror [0], [1]
     __shared__ uint32_t s_m[RW32];              // match words
     __shared__ uint32_t s_hit[R];               // tile had a match
+    front_housekeeping(a);
 
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;

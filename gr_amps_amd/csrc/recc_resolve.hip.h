@@ -172,6 +172,8 @@ struct CaptureArgs {
     uint32_t *status;         // bit 2: record list overflow
     uint32_t majority;        // decode mode (AMPS_RECC_FLAG_MAJORITY)
     uint8_t *burst_syms;      // optional [rec_cap][3374]: the captured symbols of record `slot` (AMPS_RECC_FLAG_KEEP_BURSTS)
+    uint32_t *done_blocks;    // workgroups of this launch that have finished (the last one publishes the header and clears it)
+    uint32_t *hdr_host;       // mapped pinned {nrecords, status} of the record list: what a drain reads, no copy on the stream
 };
 
 __global__ __launch_bounds__(64) void recc_capture_kernel(CaptureArgs a)
@@ -206,8 +208,22 @@ __global__ __launch_bounds__(64) void recc_capture_kernel(CaptureArgs a)
             for (int i = lane; i < AMPS_RECC_CAPTURE_SYMS; i += 64) dst[i] = s.sym[i];
         }
         if (slot < a.rec_cap) decode_burst_wave(s, c, nc, a.records + slot, a.majority != 0);
-        else { if (lane == 0) atomicOr(a.status, 4u); }
+        else { if (lane == 0) { atomicOr(a.status, 4u); __threadfence(); } }   // rare: performed before this workgroup counts itself done
         __syncthreads();
+    }
+    // the workgroup that finishes last publishes the list's running {count, status} to host memory: drain_begin needs no
+    // device-to-host copy on the stream (4.4 us of it per push in the pipelined flow).  Only the workgroups that had a capture
+    // (and workgroup 0) take part.  No fence here: a fence would wait for this workgroup's record stores to cross PCIe (measured:
+    // +30 us per launch); the header needs only the two device-side counters, and the slot counter's atomic has returned
+    // its value to this wave before the one below is issued.
+    const uint32_t nb = ncap < gridDim.x ? (ncap ? ncap : 1u) : gridDim.x;
+    if (lane == 0 && blockIdx.x < nb) {
+        const uint32_t t = atomicAdd(a.done_blocks, 1u);
+        if (t == nb - 1) {
+            a.hdr_host[0] = atomicAdd(a.nrecords, 0u);
+            a.hdr_host[1] = atomicOr(a.status, 0u);
+            atomicExch(a.done_blocks, 0u);
+        }
     }
 }
 
