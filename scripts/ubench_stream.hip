@@ -106,6 +106,40 @@ __global__ __launch_bounds__(64 * NW) void k_wg(const float4 *p, size_t ld4, int
     if (acc == 12345.f) out[0] = acc;
 }
 
+// D: sweep order with self-contained tiles: every wave also re-reads the 2 KiB in front of its tile (the neighbouring wave's data:
+// L2 / MALL hits) and does 1.5x the arithmetic -- the shape of a streaming kernel whose tiles carry their own history
+template <int WORK>
+__global__ __launch_bounds__(256) void k_sweep_halo(const float4 *p, size_t n4, float *out)
+{
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t W = (size_t)gridDim.x * 4, g = (size_t)blockIdx.x * 4 + wv;
+    const size_t total = n4 / 256;
+    float acc = 0.f;
+    float4 cur[6];
+    auto load = [&](size_t t) {
+        const float4 *b = p + t * 256 + lane;
+#pragma unroll
+        for (int q = 0; q < 4; q++) cur[q] = b[64 * q];
+        const float4 *h = t ? b - 128 : b;
+        cur[4] = h[0]; cur[5] = h[64];
+    };
+    if (g < total) load(g);
+    for (size_t t = g; t < total; t += W) {
+        float4 c[6];
+#pragma unroll
+        for (int q = 0; q < 6; q++) c[q] = cur[q];
+        if (t + W < total) load(t + W);
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            float x = c[q].x, y = c[q].y, z = c[q].z, w = c[q].w;
+#pragma unroll
+            for (int r = 0; r < WORK; r++) { x = __builtin_fmaf(x, y, z); y = __builtin_fmaf(y, z, w); z = __builtin_fmaf(z, w, x); w = __builtin_fmaf(w, x, y); }
+            acc += x + y + z + w;
+        }
+    }
+    if (acc == 12345.f) out[0] = acc;
+}
+
 template <typename F> float time_ms(F f, int reps = 10)
 {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -140,6 +174,10 @@ int main()
             run(k_wg<1, 20, 0, 4, false>, 4, wpc, 64, "coop        ");
             run(k_wg<1, 20, 0, 16, false>, 16, 16, 16, "coop        ");
         }
+    }
+    for (int wgs_per_cu : { 8, 4, 3 }) {
+        ms = time_ms([&] { hipLaunchKernelGGL((k_sweep_halo<20>), dim3(256 * wgs_per_cu), dim3(256), 0, 0, d, bytes / 16, out); });
+        printf("sweep+halo(1.5x) waves/CU %2d : %.3f ms  %.0f GB/s useful\n", wgs_per_cu * 4, ms, bytes / ms / 1e6);
     }
     for (int wgs_per_cu : { 8, 4 }) {
         const int tpc = 52;
