@@ -403,6 +403,8 @@ def fused_push_all(iq_2d, sps=10, block=None, tolerance=0, majority=False, slice
         n = iq_2d.shape[1]
         step = n if not block else block
         for off in range(0, n, step):
-            recs.append(f.push(iq_2d[c, off:off + step]))
+            blk = iq_2d[c, off:off + step]
+            # an accepted burst holds the search off for 3448 symbols: the record buffer can never be too small
+            recs.append(f.push(blk, cap=max(64, blk.shape[0] // (3000 * sps) + 16)))
     r = np.concatenate(recs) if recs else np.zeros(0, BURST_DTYPE)
     return r[np.lexsort((r["position"], r["channel"]))]

@@ -542,6 +542,36 @@ def test_more_trigger_hits_than_one_resolve_pass_holds(gpu):
         assert got.tobytes() == want.tobytes()
 
 
+def test_one_long_channel_takes_the_wide_resolve_kernel(gpu):
+    """One channel pushed 3.3 M samples at a time is cut into several hundred wave segments: the 1024-lane resolve kernel
+    compacts their hit lists, and with a truncated burst every 150 symbols it holds more hits (7000) than its LDS window
+    (2048) as well, so it walks them in passes.  Records equal to the CPU model's, in one push and in three."""
+    sps = 3
+    rng = np.random.default_rng(777)
+    _, _, _, _, words = synth.random_message(rng)
+    full = synth.burst_bits(words, dcc=2, rng=rng)
+    bursts, off = [], 3000
+    for i in range(7000):
+        whole = i % 211 == 100
+        bursts.append((off, full if whole else full[:60]))
+        off += (len(full) * 2 + 40) * sps if whole else 150 * sps
+    N = off + 12000
+    iq = synth.fsk_modulate(N, bursts, sps=sps, fs=20e3 * sps, snr_db=30.0, rng=rng)[None, :]
+    want = oracle.fused_push_all(iq, sps=sps)
+    assert len(want) >= 30
+    for blocks in ([N], [N // 3, N // 3, N]):
+        with capi.Recc(n_channels=1, sps=sps, max_samples=N, max_bursts=1024) as r:
+            o, recs = 0, []
+            for b in blocks:
+                b = min(b, N - o)
+                r.push_iq(np.ascontiguousarray(iq[:, o:o + b]))
+                recs.append(r.drain())
+                o += b
+            got = np.concatenate(recs)
+        got = got[np.lexsort((got["position"], got["channel"]))]
+        assert got.tobytes() == want.tobytes()
+
+
 @pytest.mark.parametrize("sps", [3, 4, 5, 6, 8, 10, 12])
 def test_every_supported_sample_rate_matches_the_cpu_model(gpu, sps):
     """The front kernel is instantiated per samples-per-symbol (boxcar length, correlator stride, dedup window all depend
