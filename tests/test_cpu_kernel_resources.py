@@ -1,0 +1,48 @@
+"""not gpu: the occupancy-critical kernels stay inside their register / LDS budgets (hipcc's own kernel-resource-usage report for
+gfx950, cross-compiled here).  A change that pushes one of them over silently halves its occupancy on the MI355X: the filter
+bank needs 3 waves per SIMD beside 136 KB of LDS (<= 168 VGPRs, no scratch), the streaming kernel 4 (<= 128 VGPRs)."""
+import pytest
+
+from gr_amps_amd import build
+
+
+@pytest.fixture(scope="module")
+def res():
+    return build.kernel_resources()
+
+
+def _one(res, prefix):
+    hits = {k: v for k, v in res.items() if k.startswith(prefix)}
+    assert hits, prefix
+    return hits
+
+
+def test_filter_bank_kernel_budget(res):
+    for name, r in _one(res, "void amps::chz12_kernel<8, ").items():
+        assert r["vgprs"] <= 168 and r["scratch_bytes_per_lane"] == 0 and r["vgpr_spill"] == 0, (name, r)
+        assert r["waves_per_simd"] == 3, (name, r)                     # 12 waves per workgroup, one workgroup per CU
+        assert r["lds_bytes"] == 139264, (name, r)                     # 2 x 8 frames, conflict-free padding
+
+
+def test_streaming_kernel_budget(res):
+    for sps in (3, 4, 5, 6, 8, 10, 12):
+        for name, r in _one(res, "void amps::recc_front_kernel<%d, 1, false, false, " % sps).items():
+            assert r["vgprs"] <= 128 and r["waves_per_simd"] == 4, (name, r)
+            assert r["scratch_bytes_per_lane"] <= 64, (name, r)        # a few spilled loop invariants, none in the tile loop
+            assert r["lds_bytes"] <= 40 * 1024, (name, r)              # four workgroups per CU
+
+
+def test_small_kernels_fit_many_per_cu(res):
+    for name, r in _one(res, "void amps::recc_bits_kernel<3, false>").items():
+        assert r["vgprs"] <= 64 and r["lds_bytes"] <= 4096 and r["scratch_bytes_per_lane"] == 0, (name, r)
+    for name, r in _one(res, "void amps::recc_resolve_kernel<256, 512>").items():
+        assert r["vgprs"] <= 64 and r["lds_bytes"] <= 16 * 1024, (name, r)
+    for name, r in _one(res, "amps::recc_capture_kernel").items():
+        assert r["lds_bytes"] <= 16 * 1024 and r["vgprs"] <= 168, (name, r)   # 12 bursts in flight per CU
+
+
+def test_no_kernel_spills_into_the_hot_path_unnoticed(res):
+    """every kernel of the library is listed; anything with more than 256 B of scratch per lane would be a rewrite gone wrong"""
+    assert len(res) >= 100
+    worst = max(res.items(), key=lambda kv: kv[1].get("scratch_bytes_per_lane", 0))
+    assert worst[1].get("scratch_bytes_per_lane", 0) <= 256, worst
