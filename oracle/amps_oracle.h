@@ -28,7 +28,12 @@
  *        mirror symmetry, DC gain, band-limited interpolation error) -- NOT GNU Radio's literal
  *        tables: the MMSE rows are the closed-form least-squares solution of the same objective,
  *        equal to the shipped table only to its print precision
- *   still unpinned: R5/R8 control flow of bursts_message beyond the cited lines read side by side;
+ *   R5/R8 bursts_message control flow
+ *        a SECOND restatement written apart from this one (tests/refdecode.py: Python over lists, BCH verdict from
+ *        tests/bchref.py) agrees with this library and with the HIP kernel on every field of random bursts steered
+ *        into all seven message classes, with bit errors and non-Manchester pairs (tests/test_second_restatement.py)
+ *        -- two restatements by the same hand, not a reference vector
+ *   still unpinned: what only a build of the reference could confirm:
  *        G3's loop arithmetic (clock_recovery_mm_ff) and G1's rotator renormalisation period, which
  *        only a GNU Radio build could confirm; word-level equality with the restated chain is
  *        self-consistency, not reference parity.
