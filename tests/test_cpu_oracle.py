@@ -324,3 +324,25 @@ def test_fused_model_discriminator_tolerance_and_golden():
     rec = oracle.fused_push_all(xg[None, :])
     assert rec.view(np.uint8).tobytes() == GOLD["iq_records"].tobytes()
     assert rec[0]["min"].decode() == str(GOLD["iq_truth_min"][0])
+
+
+def test_round2_golden_slicer_specs():
+    """tests/golden/recc_golden_r02.npz (make_golden_r02.py): the oracle's records for slicer specs B and C on the round-1 IQ
+    block, and records + slicer bit streams of all three specs on a 10 dB block where they are not the same"""
+    import hashlib
+    g2 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "recc_golden_r02.npz"))
+    xg = (GOLD["iq_i16"].astype(np.float32) / 8192.0).view(np.complex64)
+    for code, name in ((1, "product"), (2, "sine")):
+        assert oracle.fused_push_all(xg[None, :], slicer=code).view(np.uint8).tobytes() == g2["iq_records_" + name].tobytes()
+    xn = (g2["noisy_i8"].astype(np.float32) / 48.0).view(np.complex64).reshape(2, -1)
+    streams = {}
+    for code, name in ((0, "atan"), (1, "product"), (2, "sine")):
+        assert oracle.fused_push_all(xn, slicer=code).view(np.uint8).tobytes() == g2["noisy_records_" + name].tobytes()
+        for c in range(2):
+            f = oracle.Fused(c, 10, 0, False, code)
+            f.push(xn[c])
+            bits = f.taps()[2]
+            assert hashlib.sha256(bits.tobytes()).hexdigest() == str(g2["noisy_bits_sha_" + name][c])
+            streams[(name, c)] = bits
+    assert (streams[("atan", 0)] != streams[("sine", 0)]).any() and (streams[("atan", 0)] != streams[("product", 0)]).any()
+

@@ -146,3 +146,28 @@ def test_product_slicer_wideband_fused_unfused_and_cpu_model(gpu, spec, sid):
         a = r.drain()
     for f in WORD_FIELDS:
         assert np.array_equal(a[f], outs[0][f]), f
+
+
+def test_round2_golden_fixture_on_the_device(gpu):
+    """the committed round-2 vectors (tests/golden/recc_golden_r02.npz): records of specs B and C on the round-1 IQ block, records
+    and slicer bit streams (sha256 of the hard-decision tap) of all three specs on the 10 dB block"""
+    import hashlib
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    g1 = np.load(os.path.join(here, "golden", "recc_golden.npz"))
+    g2 = np.load(os.path.join(here, "golden", "recc_golden_r02.npz"))
+    x = (g1["iq_i16"].astype(np.float32) / 8192.0).view(np.complex64)
+    xn = (g2["noisy_i8"].astype(np.float32) / 48.0).view(np.complex64).reshape(2, -1)
+    for name in ("atan", "product", "sine"):
+        if name != "atan":
+            with capi.Recc(n_channels=1, sps=10, max_samples=65536, max_bursts=16, slicer=name) as r:
+                r.push_iq(x[None, :])
+                assert r.drain().view(np.uint8).tobytes() == g2["iq_records_" + name].tobytes()
+        with capi.Recc(n_channels=2, sps=10, max_samples=xn.shape[1], max_bursts=16, slicer=name) as r:
+            r.push_iq(xn)
+            assert r.drain().view(np.uint8).tobytes() == g2["noisy_records_" + name].tobytes()
+        for c in range(2):
+            with capi.Recc(n_channels=1, sps=10, max_samples=xn.shape[1], max_bursts=16, slicer=name) as r:
+                bits = r.debug_demod(xn[c])[2]
+            assert hashlib.sha256(bits.tobytes()).hexdigest() == str(g2["noisy_bits_sha_" + name][c]), (name, c)
+
