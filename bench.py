@@ -56,6 +56,7 @@ def parse(argv=None):
     ap.add_argument("--prewarm-ms", type=float, default=400.0, help="untimed clock-settling run of the same step before the warmup steps")
     ap.add_argument("--no-pipeline", action="store_true", help="drain synchronously after every push instead of one step behind")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-power-sample", action="store_true", help="do not sample package power / shader clock with rocm-smi during the timed region")
     ap.add_argument("--no-other-specs", action="store_true", help="skip the short runs of the other slicer specs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args(argv)
@@ -232,6 +233,55 @@ def profile_traffic(key):
     return None
 
 
+# ----------------------------------------------------------------------------------------------------- power / clock sampler
+class SmiSampler:
+    """Samples package power and shader clock with rocm-smi (a subprocess per sample, on the host only) while the timed region
+    runs, so that the bench line says in what state the number was measured (the wideband stream sits on the
+    package power limit).  Absent or failing rocm-smi -> no field."""
+
+    def __init__(self, device, period=0.7):
+        import shutil
+        import threading
+        self.exe = shutil.which("rocm-smi")
+        self.device, self.period = device, period
+        self.samples, self._stop = [], threading.Event()
+        self._t = threading.Thread(target=self._run, daemon=True) if self.exe else None
+
+    def _one(self):
+        import subprocess
+        try:
+            out = subprocess.run([self.exe, "-d", str(self.device), "--showpower", "--showclocks", "--json"], stdout=subprocess.PIPE,
+                                 stderr=subprocess.DEVNULL, timeout=5, text=True).stdout
+            card = next(iter(json.loads(out).values()))
+            power = next((float(v) for k, v in card.items() if "Power" in k and "(W)" in k), None)
+            sclk = next((v for k, v in card.items() if k.startswith("sclk")), None)
+            mhz = float("".join(ch for ch in str(sclk) if ch.isdigit() or ch == ".")) if sclk else None
+            if power is not None and mhz is not None:
+                self.samples.append((power, mhz))
+        except Exception:
+            pass
+
+    def _run(self):
+        while not self._stop.wait(self.period):
+            self._one()
+
+    def start(self):
+        if self._t:
+            self._t.start()
+
+    def stop(self):
+        if not self._t:
+            return None
+        self._stop.set()
+        self._t.join(timeout=6)
+        if len(self.samples) < 2:
+            return None
+        p = [x[0] for x in self.samples]
+        f = [x[1] for x in self.samples]
+        return {"package_w_mean": round(sum(p) / len(p), 1), "package_w_max": round(max(p), 1), "sclk_mhz_mean": round(sum(f) / len(f), 1),
+                "samples": len(p), "source": "rocm-smi --showpower --showclocks every %.1f s during the timed region" % self.period}
+
+
 # ----------------------------------------------------------------------------------------------------- one workload
 def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, warmup, light=False):
     """Build the resident batch, warm up, time exactly `steps` steps (barrier + synchronize on both sides,
@@ -332,6 +382,9 @@ def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, w
         torch.cuda.synchronize()
 
     barrier()
+    smi = SmiSampler(local) if (rank == 0 and not light and steps >= 4000 and not a.no_power_sample) else None    # only regions of a couple of seconds
+    if smi:
+        smi.start()
     t0 = time.perf_counter()
     nrec = 0
     if a.no_pipeline:
@@ -350,6 +403,7 @@ def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, w
     torch.cuda.synchronize()
     barrier()
     el = time.perf_counter() - t0
+    power = smi.stop() if smi else None
     if dist is not None:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -409,6 +463,8 @@ def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, w
                              "kernel": kname, "kernel_ms": round(kms, 4),
                              "note": "algorithmic flops of the same kernel (model in bench.py: chz_flops_per_frame / front_flops_per_sample) over the same in-run HIP-event duration"},
     }
+    if power:
+        res["power"] = power
     return res, iq_base
 
 
@@ -448,6 +504,7 @@ def main(argv=None):
         "scaling": "weak" if (a.dist == "bands" or world == 1) else "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": res["config"], "roofline": res["roofline"], "roofline_compute": res["roofline_compute"], "prewarm_ms": a.prewarm_ms,
+        "power": res.get("power"),
         "dist": a.dist,
     }
     if world == 1 and not a.no_other_specs:
