@@ -52,7 +52,7 @@ def parse(argv=None):
                          "sine = spec C (the same without the arctangent), product = spec B.  The other specs' kernel times are reported under 'other_slicer_specs'")
     ap.add_argument("--dist", default="bands", choices=["bands", "broadcast", "scatter_allgather"])
     ap.add_argument("--samples", type=int, default=0, help="per-channel samples per step (0 = workload default)")
-    ap.add_argument("--taps", type=int, default=8, choices=[8, 16], help="wideband832: prototype taps per polyphase branch")
+    ap.add_argument("--taps", type=int, default=8, choices=[8], help="wideband832: prototype taps per polyphase branch")
     ap.add_argument("--prewarm-ms", type=float, default=400.0, help="untimed clock-settling run of the same step before the warmup steps")
     ap.add_argument("--no-pipeline", action="store_true", help="drain synchronously after every push instead of one step behind")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -417,7 +417,7 @@ def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, w
     if wide:   # dominant kernel = the channelizer; algorithmic bytes = the wideband block read once (14.77 B/symbol at 832 channels)
         kms = tm["ms_channelizer"] / max(1, tm["launches_channelizer"])
         alg_bytes = 8.0 * NW
-        kname = "chz12_kernel<%d, slicer %s>" % (a.taps, SLICERS[slicer]) if a.taps == 8 else "chz_fused_kernel<16>"
+        kname = "chz12_kernel<%d, slicer %s>" % (a.taps, SLICERS[slicer])
         flops = chz_flops_per_frame(a.taps, slicer, C) * (NW / 512.0)
         note = ("filter bank (fold + FFT-1024 = 4 x 16 x 16) + slicer spec %s in one kernel, %.1f flop per input byte: bound by VALU issue "
                 "and LDS exchange, not by HBM (both rooflines are reported; the HBM fraction is what the metric asks for).  Only slicer bits "

@@ -21,6 +21,13 @@ FLAG_UNFUSED_WIDEBAND = 4
 FLAG_SLICER_PRODUCT = 8
 FLAG_SLICER_SINE = 16
 FLAG_KEEP_BURSTS = 32
+FLAG_SLICER_ATAN = 64
+
+# slicer names accepted by Recc(slicer=...): numeric spec of include/amps_recc_numerics.h -> cfg flag
+_SLICER_FLAGS = {None: 0, "default": 0, "atan": FLAG_SLICER_ATAN, 0: FLAG_SLICER_ATAN, "A": FLAG_SLICER_ATAN,
+                 "product": FLAG_SLICER_PRODUCT, 1: FLAG_SLICER_PRODUCT, "B": FLAG_SLICER_PRODUCT,
+                 "sine": FLAG_SLICER_SINE, 2: FLAG_SLICER_SINE, "C": FLAG_SLICER_SINE}
+SLICER_NAMES = ("atan", "product", "sine")      # indexed by AMPS_SLICER_*
 
 MSG_CLASSES = ("invalid_word_a", "e_zero", "page_response", "registration", "origination", "bad_nawc", "unknown")
 
@@ -87,7 +94,7 @@ EXPORTS = (
     "amps_recc_set_xlate", "amps_recc_push_raw", "amps_recc_debug_xlate", "amps_recc_set_timing",
     "amps_recc_drain_begin", "amps_recc_drain_end", "amps_recc_set_origin",
     "amps_recc_wait_event", "amps_recc_record_event", "amps_recc_refchain_symbols", "amps_recc_refchain_tables",
-    "amps_recc_drain_bursts",
+    "amps_recc_drain_bursts", "amps_recc_default_slicer",
 )
 
 _lib = None
@@ -111,6 +118,7 @@ def load():
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.amps_recc_abi_version.restype = C.c_int
+    L.amps_recc_default_slicer.restype = C.c_int
     L.amps_recc_strerror.argtypes = [C.c_int]
     L.amps_recc_strerror.restype = C.c_char_p
     L.amps_recc_burst_size.restype = C.c_size_t
@@ -176,9 +184,13 @@ class Recc:
     """One handle = `n_channels` independent RECC receivers on one MI355X."""
 
     def __init__(self, n_channels=1, sps=10, max_samples=0, max_bursts=1024, device=-1, time_kernels=False,
-                 stream=None, wideband=None, majority=False, unfused_wideband=False, sync_tolerance=0, slicer="atan",
+                 stream=None, wideband=None, majority=False, unfused_wideband=False, sync_tolerance=0, slicer="default",
                  sync_torch=True, keep_bursts=False):
         L = load()
+        if isinstance(slicer, bool) or slicer not in _SLICER_FLAGS:        # a typo must not run a different numeric spec silently
+            raise ValueError("slicer must be one of %r" % sorted(map(str, _SLICER_FLAGS)))
+        self.slicer = SLICER_NAMES[L.amps_recc_default_slicer()] if _SLICER_FLAGS[slicer] == 0 else \
+            {FLAG_SLICER_ATAN: "atan", FLAG_SLICER_PRODUCT: "product", FLAG_SLICER_SINE: "sine"}[_SLICER_FLAGS[slicer]]
         self.sync_torch = sync_torch
         cfg = Cfg()
         cfg.struct_size = C.sizeof(Cfg)
@@ -189,8 +201,7 @@ class Recc:
         cfg.device = device
         cfg.flags = ((FLAG_TIME_KERNELS if time_kernels else 0) | (FLAG_MAJORITY if majority else 0)
                      | (FLAG_UNFUSED_WIDEBAND if unfused_wideband else 0)
-                     | (FLAG_SLICER_PRODUCT if slicer in ("product", 1) else 0)
-                     | (FLAG_SLICER_SINE if slicer in ("sine", 2) else 0)
+                     | _SLICER_FLAGS[slicer]
                      | (FLAG_KEEP_BURSTS if keep_bursts else 0))
         cfg.stream = stream
         cfg.sync_tolerance = sync_tolerance

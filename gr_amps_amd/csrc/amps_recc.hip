@@ -14,7 +14,6 @@
 #include "amps_recc.h"
 #include "amps_recc_numerics.h"
 #include "recc_front.hip.h"
-#include "recc_front_coop.hip.h"
 #include "recc_resolve.hip.h"
 #include "recc_symbols.hip.h"
 #include "recc_channelizer.hip.h"
@@ -56,13 +55,12 @@ struct amps_recc {
     int carry_cur = 0;
     uint64_t n_done = 0;
     uint64_t origin = 0;              // absolute index of the stream's first sample (amps_recc_set_origin)
-    int slicer = AMPS_SLICER_ATAN_BOXCAR;   // numeric spec of the slicer (AMPS_RECC_FLAG_SLICER_PRODUCT selects spec B)
+    int slicer = AMPS_SLICER_DEFAULT;       // numeric spec of the slicer (AMPS_RECC_FLAG_SLICER_* select one explicitly)
     uint32_t r_prev = 0;
     bool origin_locked = false;       // a push has happened since the last reset
     uint64_t *gring = nullptr;
     uint32_t ring_words = 0;
     uint32_t max_waves = 0, max_chunks = 0, det_cap = 0;   // front-launch geometry bounds (see run_iq_device)
-    uint32_t coop_w = 0, max_wgs_coop = 0;                 // cooperative front kernel: waves per workgroup (0 = not used), resident workgroups
     uint32_t max_waves_bits = 0;                           // the same for the bit-domain kernel (more waves fit: 72 VGPRs, 2 KB LDS)
     uint64_t *det = nullptr;
     uint32_t *detcount = nullptr;
@@ -80,6 +78,7 @@ struct amps_recc {
     uint8_t *bsym_host_buf[2] = { nullptr, nullptr }, *bsym_dev_buf[2] = { nullptr, nullptr };   // AMPS_RECC_FLAG_KEEP_BURSTS: [max_bursts][3374], mapped pinned
     uint32_t *nrecords_buf[2] = { nullptr, nullptr }, *status_buf[2] = { nullptr, nullptr };
     int cur_buf = 0, open_buf = -1;
+    bool open_untouched = false;      // no push has been enqueued since drain_begin: the open list's device counters are still there (header cross-check)
     hipEvent_t drain_event = nullptr;
     float2 *stage_iq = nullptr;       // device staging for host-resident IQ
     size_t stage_iq_samples = 0;
@@ -246,6 +245,17 @@ int reset_state(amps_recc *h)
     return 0;
 }
 
+// AMPS_RECC_CHECK_HEADER=1 (the GPU test suite sets it): a drain that finds the stream idle behind it compares the header the
+// capture kernel's last workgroup published to host memory with the list's device-side counters.  The publish orders three
+// relaxed device atomics by their completion (recc_resolve.hip.h); this check is what would notice a compiler or architecture
+// change breaking that.
+bool check_header_enabled()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = std::getenv("AMPS_RECC_CHECK_HEADER"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
 bool bits_kernel_is_front()   // AMPS_RECC_BITS_KERNEL=front: search the bit ring with recc_front_kernel<3,1,BITS> (cross-check)
 {
     static int v = -1;
@@ -315,55 +325,6 @@ template <int SPS> void launch_front(const FrontArgs &fa, dim3 grid, hipStream_t
     }
 }
 
-// cooperative form (recc_front_coop.hip.h): the 4 waves of a workgroup on 4 consecutive tiles.  Opt-in (AMPS_RECC_COOP=4):
-// measured equal to the wave-private kernel within the run-to-run spread for spec C, slower for spec A
-constexpr int COOP_W = 4;
-template <int SPS> int coop_blocks_per_cu_t(int slicer)
-{
-    int n = 0;
-    hipError_t e = slicer == AMPS_SLICER_SINE
-        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, recc_front_coop_kernel<SPS, COOP_W, AMPS_SLICER_SINE>, 64 * COOP_W, 0)
-        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, recc_front_coop_kernel<SPS, COOP_W, AMPS_SLICER_ATAN_BOXCAR>, 64 * COOP_W, 0);
-    return (e == hipSuccess && n > 0) ? n : 1;
-}
-template <int SPS> void launch_coop_t(const FrontArgs &fa, dim3 grid, hipStream_t s, int slicer)
-{
-    if (slicer == AMPS_SLICER_SINE) hipLaunchKernelGGL((recc_front_coop_kernel<SPS, COOP_W, AMPS_SLICER_SINE>), grid, dim3(64 * COOP_W), 0, s, fa);
-    else hipLaunchKernelGGL((recc_front_coop_kernel<SPS, COOP_W, AMPS_SLICER_ATAN_BOXCAR>), grid, dim3(64 * COOP_W), 0, s, fa);
-}
-int coop_blocks_per_cu(uint32_t sps, int slicer)
-{
-    switch (sps) {
-    case 3: return coop_blocks_per_cu_t<3>(slicer);
-    case 4: return coop_blocks_per_cu_t<4>(slicer);
-    case 5: return coop_blocks_per_cu_t<5>(slicer);
-    case 6: return coop_blocks_per_cu_t<6>(slicer);
-    case 8: return coop_blocks_per_cu_t<8>(slicer);
-    case 10: return coop_blocks_per_cu_t<10>(slicer);
-    case 12: return coop_blocks_per_cu_t<12>(slicer);
-    default: return 0;
-    }
-}
-int dispatch_coop(uint32_t sps, const FrontArgs &fa, dim3 grid, hipStream_t s, int slicer)
-{
-    switch (sps) {
-    case 3: launch_coop_t<3>(fa, grid, s, slicer); break;
-    case 4: launch_coop_t<4>(fa, grid, s, slicer); break;
-    case 5: launch_coop_t<5>(fa, grid, s, slicer); break;
-    case 6: launch_coop_t<6>(fa, grid, s, slicer); break;
-    case 8: launch_coop_t<8>(fa, grid, s, slicer); break;
-    case 10: launch_coop_t<10>(fa, grid, s, slicer); break;
-    case 12: launch_coop_t<12>(fa, grid, s, slicer); break;
-    default: return -EINVAL;
-    }
-    return 0;
-}
-bool coop_wanted()   // read at every create
-{
-    const char *e = std::getenv("AMPS_RECC_COOP");
-    return e && std::atoi(e) == COOP_W;
-}
-
 bool sps_supported(uint32_t sps)
 {
     switch (sps) { case 3: case 4: case 5: case 6: case 8: case 10: case 12: return true; default: return false; }
@@ -390,6 +351,7 @@ int dispatch_front(uint32_t sps, const FrontArgs &fa, dim3 grid, hipStream_t s, 
 // idle list's device counters are free to be cleared by any later launch.  Two memsets and one copy fewer per push.
 void front_housekeeping_args(amps_recc *h, FrontArgs &fa)
 {
+    h->open_untouched = false;              // this launch may clear the counters of the list a split drain has open
     fa.zero1 = h->capq_count;
     const int idle = h->cur_buf ^ 1;
     fa.zero2 = h->list_clean[idle] ? nullptr : h->nrecords_buf[idle];
@@ -417,10 +379,7 @@ int run_iq_device(amps_recc *h, const float2 *iq, uint64_t ld, uint32_t nsamp)
     // geometry of the persistent front launch
     const uint32_t Tc = (P + TILE - 1) / TILE;
     const uint64_t G = (uint64_t)h->C * Tc;
-    // segment owners: waves (recc_front_kernel) or workgroups of coop_w waves (recc_front_coop_kernel; not with the debug taps)
-    const uint32_t coop = (h->coop_w && !h->dbg_d) ? h->coop_w : 0u;
-    const uint64_t min_span = coop ? MIN_SPAN * coop : MIN_SPAN;
-    uint32_t nwaves = (uint32_t)std::min<uint64_t>(coop ? h->max_wgs_coop : h->max_waves, (G + min_span - 1) / min_span);
+    uint32_t nwaves = (uint32_t)std::min<uint64_t>(h->max_waves, (G + MIN_SPAN - 1) / MIN_SPAN);
     if (nwaves == 0) nwaves = 1;
     const uint32_t span = (uint32_t)((G + nwaves - 1) / nwaves);
     if (P && (uint64_t)(Tc + span - 1) / span + 1 > h->max_chunks) return -E2BIG;
@@ -438,8 +397,7 @@ int run_iq_device(amps_recc *h, const float2 *iq, uint64_t ld, uint32_t nsamp)
         if (debug_sync_enabled())
             std::fprintf(stderr, "amps_recc[debug]: front waves=%u span=%u Tc=%u C=%u P=%u avail=%u r_prev=%u ld=%llu n_done=%llu ring_words=%u max_chunks=%u det_cap=%u\n",
                          nwaves, span, Tc, h->C, P, avail, h->r_prev, (unsigned long long)ld, (unsigned long long)h->n_done, h->ring_words, h->max_chunks, h->det_cap);
-        int rc = coop ? dispatch_coop(h->sps, fa, dim3(nwaves), s, h->slicer)
-                      : dispatch_front(h->sps, fa, dim3((nwaves + 3) / 4), s, h->slicer);
+        int rc = dispatch_front(h->sps, fa, dim3((nwaves + 3) / 4), s, h->slicer);
         if (rc) return rc;
     }
     if (int rc = debug_sync(h, "front")) return rc;
@@ -488,6 +446,7 @@ int run_iq_device(amps_recc *h, const float2 *iq, uint64_t ld, uint32_t nsamp)
 extern "C" {
 
 int amps_recc_abi_version(void) { return AMPS_RECC_ABI_VERSION; }
+int amps_recc_default_slicer(void) { return AMPS_SLICER_DEFAULT; }
 size_t amps_recc_burst_size(void) { return sizeof(amps_recc_burst_t); }
 
 const char *amps_recc_strerror(int code)
@@ -517,7 +476,10 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
     // bit-domain kernels behind it are built for exactly that
     if (cfg->wideband_channels && (cfg->samples_per_symbol != 3 || cfg->max_samples_per_push == 0)) return -EINVAL;
     if (cfg->sync_tolerance > AMPS_RECC_MAX_SYNC_TOLERANCE) return -EINVAL;
-    if ((cfg->flags & AMPS_RECC_FLAG_SLICER_PRODUCT) && (cfg->flags & AMPS_RECC_FLAG_SLICER_SINE)) return -EINVAL;
+    {
+        const uint32_t sl = cfg->flags & (AMPS_RECC_FLAG_SLICER_PRODUCT | AMPS_RECC_FLAG_SLICER_SINE | AMPS_RECC_FLAG_SLICER_ATAN);
+        if (sl & (sl - 1)) return -EINVAL;                         // at most one slicer spec
+    }
     if (cfg->n_channels >= (1u << (64 - CAPQ_POS_BITS))) return -EINVAL;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return -ENODEV;
@@ -533,7 +495,8 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
     h->C = cfg->n_channels;
     h->sps = cfg->samples_per_symbol;
     h->slicer = (cfg->flags & AMPS_RECC_FLAG_SLICER_PRODUCT) ? AMPS_SLICER_PRODUCT
-              : (cfg->flags & AMPS_RECC_FLAG_SLICER_SINE) ? AMPS_SLICER_SINE : AMPS_SLICER_ATAN_BOXCAR;
+              : (cfg->flags & AMPS_RECC_FLAG_SLICER_SINE) ? AMPS_SLICER_SINE
+              : (cfg->flags & AMPS_RECC_FLAG_SLICER_ATAN) ? AMPS_SLICER_ATAN_BOXCAR : AMPS_SLICER_DEFAULT;
     h->timing = (cfg->flags & AMPS_RECC_FLAG_TIME_KERNELS) != 0;
     h->timing_mode = h->timing ? AMPS_RECC_TIMING_ALL : AMPS_RECC_TIMING_OFF;
     if (cfg->stream) h->stream = (hipStream_t)cfg->stream;
@@ -591,12 +554,7 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
             h->max_waves_bits = (uint32_t)prop.multiProcessorCount * 4u * (uint32_t)nb;
         }
         const uint64_t max_tiles = (maxs + 63 + TILE - 1) / TILE;
-        uint64_t max_span = std::max<uint64_t>(MIN_SPAN, (C * max_tiles + h->max_waves - 1) / h->max_waves);
-        if (cfg->sync_tolerance == 0 && h->slicer != AMPS_SLICER_PRODUCT && coop_wanted()) {
-            h->coop_w = COOP_W;
-            h->max_wgs_coop = (uint32_t)prop.multiProcessorCount * (uint32_t)coop_blocks_per_cu(h->sps, h->slicer);
-            max_span = std::max<uint64_t>(max_span, std::max<uint64_t>(MIN_SPAN * h->coop_w, (C * max_tiles + h->max_wgs_coop - 1) / h->max_wgs_coop));
-        }
+        const uint64_t max_span = std::max<uint64_t>(MIN_SPAN, (C * max_tiles + h->max_waves - 1) / h->max_waves);
         h->max_chunks = (uint32_t)(prop.multiProcessorCount * 32u / C + 3);   // bound for any occupancy
         h->det_cap = (uint32_t)(max_span * TILE / ((uint64_t)AMPS_RECC_TRIGGER_SYMS * h->sps) + 4);
         rc |= dev_alloc(&h->carry[0], C * CARRY_CAP);
@@ -975,6 +933,7 @@ int amps_recc_drain_begin(amps_recc_t *h)
     // the list's header is already on its way to host memory: the last capture workgroup of every push writes it
     HIP_TRY(hipEventRecord(h->drain_event, s));
     h->open_buf = b;
+    h->open_untouched = true;
     select_record_list(h, b ^ 1);           // later pushes append to the other list
     if (!h->list_clean[b ^ 1]) {            // drained twice with no push in between: nobody has cleared it yet
         HIP_TRY(hipMemsetAsync(h->nrecords_buf[b ^ 1], 0, 2 * sizeof(uint32_t), s));
@@ -1009,6 +968,14 @@ static int drain_end_impl(amps_recc_t *h, amps_recc_burst_t *out, uint8_t *burst
     volatile uint32_t *hdr = h->hdr_host + HDR_STRIDE * b;
     uint32_t n = hdr[0];
     const uint32_t st = hdr[1];
+    if (check_header_enabled() && h->open_untouched) {
+        uint32_t dev[2] = { 0u, 0u };
+        HIP_TRY(hipMemcpy(dev, h->nrecords_buf[b], sizeof(dev), hipMemcpyDeviceToHost));
+        if (dev[0] != n || dev[1] != st) {
+            std::fprintf(stderr, "amps_recc: published list header {%u, %u} differs from the device counters {%u, %u}\n", n, st, dev[0], dev[1]);
+            return -EIO;
+        }
+    }
     hdr[0] = 0u; hdr[1] = 0u;               // empty until a capture kernel publishes into it again (the list is not current now)
     int rc = 0;
     if (st & 1u) rc = -EOVERFLOW;

@@ -1,32 +1,25 @@
 // recc_channelizer.hip.h -- polyphase channelizer front end for gfx950: one wideband fc32 stream
-// (fs = M * 30 kHz) -> C active 30 kHz channels at fs / D, channel-major, ready for recc_front_kernel.
+// (fs = M * 30 kHz) -> C active 30 kHz channels at fs / D, with the RECC slicer fused behind the FFT.
 //
 // It stands where the reference wires one freq_xlating_fir_filter_ccc (299 complex taps, decim 2) per
 // channel in front of the RECC chain (grc/recctest.grc:889-937, taps :115-155).  Replicating that FIR per
 // channel is ~150 flop per input byte; a weighted-overlap-add filter bank does all M
-// channels at once for ~28 flop/B:
+// channels at once for ~17 flop/B:
 //     frame m:  n0 = (m+1) D - L,  L = P*M taps
 //               u[r] = sum_{i : (n0+i) mod M = r} h[i] x[n0+i]          (fold, "polyphase")
 //               Y_k[m] = FFT_M(u)[k] = sum_i h[i] x[n0+i] e^{-j 2 pi k (n0+i)/M}
 // i.e. channel k (centre k*fs/M) mixed to DC with an absolute phase reference, low-pass filtered by the
 // prototype h and decimated by D = M/2 (2x oversampled: 60 ksps = 3 samples per Manchester symbol at M = 1024).
 //
-// Mapping to the hardware (one 256-thread workgroup walks a run of consecutive frames):
-//   * polyphase delay lines live in REGISTERS: thread t owns the four branches with residue t + 256 jb (mod M).
-//     A frame adds D = 512 new samples, read with one coalesced 4 KiB load (prefetched one frame ahead), and the
-//     two samples a thread loads are exactly the ones its own branches need -- there is no LDS sample window at
-//     all (a first version kept a 64 KiB LDS ring: 80 KiB per workgroup, two workgroups per CU, 32 LDS reads and
-//     64 address instructions per thread per frame);
-//   * the fold is one v_pk_fma per tap against 4P register-resident coefficients; which coefficient set a branch
-//     uses alternates with the frame parity, so the frame loop is unrolled by two parities (by eight, see below);
-//   * FFT-1024 = Stockham passes of radix 4, 16, 4, 4 over a BATCH of four frames: pass 1 runs on the registers the
-//     fold just produced, the radix-16 pass is done by one wave per frame entirely in registers (in place in LDS),
-//     the last pass leaves bins {t, t+256, t+512, t+768} in registers -- so a thread owns the same four channels in
-//     every frame.  Three workgroup barriers per four frames.  Twiddles of the radix-4 passes are per-thread
-//     constants (12 registers), those of the radix-16 pass a 512-byte LDS table;
-//   * eight frames of a thread's four bins are kept in registers and written as 64-byte runs into the
-//     channel-major output (dwordx4 stores), which recc_front_kernel then streams at full rate.
-// No MFMA: the contraction per channel is 8..16 taps deep and the FFT is a butterfly network.
+// Mapping to the hardware: ONE 768-thread workgroup owns a CU and its twelve waves split three ROLES, four waves each, so
+// that every SIMD holds one wave of each role -- a VALU-dense one, and two that alternate LDS round trips with VALU work in
+// different phases (chz12_kernel below):
+//   fold  : polyphase delay lines in a register ring, the fold as v_pk_fma chains, radix-4 pass 1 on its own registers
+//   pass 2: radix 16, one frame per wave, in place in LDS
+//   pass 3: radix 16 (FFT-1024 = 4 x 16 x 16), then the slicer: a lane owns the same four channels for ever
+// Half-batches of four frames travel through a four-slot LDS ring (16 frame buffers, 136 KB), one workgroup barrier per four
+// frames.  Only slicer bits (1/64 of the input) reach HBM.  No MFMA: the contraction per channel is 8 taps deep and differs per
+// branch, and the FFT is a butterfly network (a DFT-16 as a matrix product costs 12x its flops at the f32 MFMA rate = the VALU rate).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cerrno>
@@ -65,7 +58,6 @@ struct StageFence {
 
 constexpr int CHZ_M = 1024;          // branches = FFT size
 constexpr int CHZ_D = 512;           // input samples per frame (2x oversampled)
-constexpr int CHZ_GROUP = 8;         // frames buffered in registers per output store (64-byte runs)
 
 struct ChzArgs {
     const float2 *block;     // new wideband samples of this push
@@ -76,7 +68,7 @@ struct ChzArgs {
     uint32_t carry_len;      // L - D + leftover
     uint32_t nsamp;          // new samples
     uint32_t nframes;        // frames produced by this launch
-    uint32_t frames_per_wg;  // multiple of CHZ_GROUP
+    uint32_t frames_per_wg;  // multiple of 64
     uint32_t first_bin;      // FFT bin of channel 0
     uint32_t n_channels;
     uint32_t odd_start;      // parity of (absolute frame index of frame 0 of this launch)
@@ -87,7 +79,7 @@ struct ChzArgs {
     uint64_t n_done;         // absolute channel-stream sample index of frame 0 (multiple of 64)
     uint32_t stream_start;   // frame 0 of this launch is the first frame of the stream (spec B: its first 3 bits are ones)
 };
-constexpr int CHZ_PRE = 4;   // frames re-run in front of a workgroup's range to rebuild per-bin demod state (even)
+constexpr int CHZ_PRE = 4;   // frames of history the carry keeps beyond the filter's own L - D samples: what the exact half of a workgroup's pre-roll reaches back to
 
 typedef float cf2 __attribute__((ext_vector_type(2)));
 
@@ -141,28 +133,12 @@ __device__ __forceinline__ cf2 fma_hi(cf2 a, cf2 c, cf2 s)
     return r;
 }
 
-// History on MI355X (1 GiB of wideband per launch, fused kernel ms): LDS sample ring 1.49 -> register delay lines 1.26 ->
-// fused discriminator 1.02 -> packed complex multiply 0.90 -> lock-step 4-way discriminator 0.87 -> two-frame prefetch 0.83
-// -> four-frame batches with a radix-16 pass 0.69 -> per-batch branch-free input path 0.67 -> packed boxcar adds 0.64.
-// Measured and rejected (kernel ms at the time): baseline 1.24; XOR-swizzled exchange
-// buffers 1.36 (33 % of LDS cycles are bank conflicts, but the kernel is latency- not LDS-bound and the index math
-// sits on the critical path); padded buffers 2.0 (LDS over 80 KiB -> one workgroup per CU, LDS-ring version);
-// 4-frame output groups + recomputed twiddle powers + __launch_bounds__(256,3) 3.9 (168 VGPRs -> spills).
 
-// ---- the frame pipeline: four frames per batch, FFT-1024 = radix 4 x 16 x 4 x 4 (Stockham) ----
-// A workgroup is four waves, and a 1024-point frame is 64 lanes x 16 points: with FOUR frames in flight the middle
-// of the FFT becomes one in-register radix-16 pass in which wave w owns frame w of the batch outright.  Per batch:
-//   fold + pass 1 (radix 4, registers -> A), all four frames            | barrier
-//   pass 2 (radix 16): wave w reads frame w of A entirely, writes it back in place   | barrier
-//   pass 3 (radix 4): A -> C, all four frames                           | barrier
-//   pass 4 (radix 4): C -> registers (bins t, t+256, t+512, t+768 of every frame)
-// = 3 barriers per 4 frames.  The first version ran five radix-4 passes per frame with 4 barriers EACH (0.85 ms -> 0.69 with
-// this pipeline; with the barriers compiled out, timing only, the current kernel runs 8 % faster, the old one 20 %).
-// Frame buffers are padded by one element per 16 (cpad) so that the radix-16 write-back (stride 16 elements between
-// lanes) does not land on four banks.
+// ---- frame geometry ----
+// A half-batch = four frames (what the fold role produces per time step); a frame buffer holds one 1024-point frame.
 constexpr int CHZ_BATCH = 4;
 constexpr int CHZ_FB = CHZ_M + CHZ_M / 16;                     // padded frame buffer, cf2 elements
-__host__ __device__ constexpr int cpad(int n) { return n + (n >> 4); }
+constexpr int CHZ_FBF = 2 * CHZ_FB;                            // ... in floats
 
 __device__ __forceinline__ void dft4(cf2 a0, cf2 a1, cf2 a2, cf2 a3, cf2 (&o)[4])
 {
@@ -178,101 +154,34 @@ __device__ __forceinline__ cf2 chz_twiddle(int num, int den)
     return (cf2){ cs, sn };
 }
 
-// One frame: fold x[jb] = sum_q h[t + 256 j + qM] * win[jb][q], j = jb ^ (2 * ((m+1) & 1)), then the radix-4 pass 1 ->
-// A[4t .. 4t+3].  The tap window of branch jb is ext[jb][S .. S+P): ext = {delay line, the batch's new samples} and S (SA for
-// branches 0,1; SB for 2,3) counts the samples of this batch already shifted in.  PAR = parity of the absolute frame index
-// m: which coefficient set a branch uses alternates with it.  All register indices are compile-time constants.
-template <int P, int PAR, int SA, int SB>
-__device__ __forceinline__ void chz_fold_p1(const cf2 (&ext)[4][P + 2], const cf2 (&coef)[4][P / 2], cf2 *A, int t)
-{
-    constexpr int SW = 2 * ((PAR + 1) & 1);
-    cf2 x[4];
-#pragma unroll
-    for (int jb = 0; jb < 4; jb++) {
-        const int sh = jb < 2 ? SA : SB;
-        cf2 s = { 0.f, 0.f };
-#pragma unroll
-        for (int q = 0; q < P; q += 2) {                            // taps q, q+1 share one coefficient pair
-            s = fma_lo(ext[jb][sh + q], coef[jb ^ SW][q / 2], s);
-            s = fma_hi(ext[jb][sh + q + 1], coef[jb ^ SW][q / 2], s);
-        }
-        x[jb] = s;
-    }
-    cf2 o[4];
-    dft4(x[0], x[1], x[2], x[3], o);                            // radix 4, p = 1: no twiddles
-    cf2 *d = A + cpad(4 * t);                                   // 4t .. 4t+3 share one 16-group
-    d[0] = o[0]; d[1] = o[1]; d[2] = o[2]; d[3] = o[3];
-}
 
-// The four frames of a batch.  Frame g brings two new samples per thread, for branches {0,1} (g even) or {2,3} (g odd).
-// The four tap windows are views of {delay line, new samples} at compile-time offsets, so within the batch nothing moves;
-// the delay lines are shifted once per batch, by two samples per branch (shifting per frame cost 150 v_mov per batch,
-// a tenth of the instruction stream).
-template <int P>
-__device__ __forceinline__ void chz_fold_batch(cf2 (&line)[4][P], const cf2 (&coef)[4][P / 2], const cf2 (&nx)[CHZ_BATCH][2], cf2 *bufA, int t)
-{
-    cf2 ext[4][P + 2];
-#pragma unroll
-    for (int jb = 0; jb < 4; jb++) {
-#pragma unroll
-        for (int q = 0; q < P; q++) ext[jb][q] = line[jb][q];
-        ext[jb][P] = nx[jb >> 1][jb & 1];                       // frames 0 / 1 feed branches {0,1} / {2,3}
-        ext[jb][P + 1] = nx[2 + (jb >> 1)][jb & 1];             // frames 2 / 3
-    }
-    chz_fold_p1<P, 0, 1, 0>(ext, coef, bufA, t);
-    chz_fold_p1<P, 1, 1, 1>(ext, coef, bufA + CHZ_FB, t);
-    chz_fold_p1<P, 0, 2, 1>(ext, coef, bufA + 2 * CHZ_FB, t);
-    chz_fold_p1<P, 1, 2, 2>(ext, coef, bufA + 3 * CHZ_FB, t);
-#pragma unroll
-    for (int jb = 0; jb < 4; jb++)
-#pragma unroll
-        for (int q = 0; q < P; q++) line[jb][q] = ext[jb][q + 2];
-}
-
-// LDS layouts of the 12-wave kernel's frame buffers (cf2 elements).  cpad's one pad element per 16 makes the 8-byte READS of 32
-// consecutive lanes span 33 elements, so lane 31 lands on lane 0's banks (one extra LDS cycle on every read of passes 2 and 3
-// and of the slicer: 17 % of the LDS cycles were bank conflicts); here every access of the pipeline is conflict free:
+// LDS layouts of a frame buffer (cf2 elements unless noted); every access of the pipeline is bank-conflict free (PMC:
+// SQ_LDS_BANK_CONFLICT = 0; a one-pad-per-16 layout cost 17 % of the LDS cycles):
 //   chz_pos1: pass-1 output, element 4 t + k1 at t + 260 k1 -- the fold's stores are stride 1 across lanes, and pass 2's gather
-//             (the compiler pairs its reads into ds_read2_b64: 16-lane groups, 16 bank pairs) hits (i >> 2) + 4 (i & 3) mod 16:
-//             with cpad, or with 264 k1, every such read was a 2-way conflict (PMC: exactly 8 conflict cycles per ds_read2);
-//   chz_pos2: pass-2 and pass-3 output, n + 4 (n >> 6): no padding inside 64 consecutive elements (reads i + 64 r of
-//             consecutive lanes are consecutive), and the stride-64 write-back of pass 2 advances 8 banks per four lanes.
+//             (the compiler pairs its reads into ds_read2_b64: 16-lane groups, 16 bank pairs) hits (i >> 2) + 4 (i & 3) mod 16;
+//   chz_pos2: pass-2 output, n + 4 (n >> 6): no padding inside 64 consecutive elements (reads i + 64 r of consecutive lanes are
+//             consecutive), and the stride-64 write-back of pass 2 advances 8 banks per four lanes;
+//   planar  : pass-3 output = the spectrum in natural order, as FLOATS, in blocks of 128 bins: [re of the block's first 64 bins |
+//             re of its last 64 | im of the first 64 | im of the last 64] -- the slicer role owns bins l and l + 64 of a block per
+//             lane, so one ds_read2st64_b32 delivers (re of its two channels) as the register PAIR that packed fp32
+//             instructions take as it is, the next one (im, im); 64 consecutive lanes read 64 consecutive floats.
 __host__ __device__ constexpr int chz_pos1(int t, int k1) { return t + 260 * k1; }
 __host__ __device__ constexpr int chz_pos2(int n) { return n + 4 * (n >> 6); }
-static_assert(chz_pos1(255, 3) < CHZ_FB && chz_pos2(1023) < CHZ_FB, "frame buffer too small for the 12-wave layouts");
+__host__ __device__ constexpr int chz_planar(int n) { return 256 * (n >> 7) + (n & 127); }   // real part; the imaginary part is 128 floats further
+static_assert(chz_pos1(255, 3) < CHZ_FB && chz_pos2(1023) < CHZ_FB && chz_planar(1023) + 128 < CHZ_FBF, "frame buffer too small for the layouts");
 
 // pass 2, radix 16, p = 4, one frame per wave, in place.  lane i: k = i & 3, u[r] = A[i + 64 r] e^{-2 pi i r k / 64},
-// X = DFT16(u), A[16 (i - k) + k + 4 r] = X[r].  tab[r][k] holds the twiddles (LDS, 512 B).
-template <bool REGS>
-__device__ __forceinline__ void chz_p2_t(cf2 *A, const cf2 *tab, const cf2 (&twr)[15], int lane)
+// X = DFT16(u), A[16 (i - k) + k + 4 r] = X[r].  The input twiddles W_64^{r k} have already been applied by the fold role
+// (chz_fold2_ring): read from an LDS table here, one pair at a time between the multiplies, they cost eight exposed LDS
+// latencies per pass (measured with s_memtime: 2950 cycles per frame against 1780 for pass 3).
+__device__ __forceinline__ void chz_p2(cf2 *A, int lane)
 {
     const int k = lane & 3;
     cf2 u[16];
-    if constexpr (REGS) {
-        // 12-wave kernel: pass 1 left element 4 t + k1 at chz_pos1(t, k1): lane i wants 4 t + k1 = i + 64 r, i.e.
-        // t = (i >> 2) + 16 r, k1 = i & 3
-        const cf2 *src = A + chz_pos1(lane >> 2, k);
+    // pass 1 left element 4 t + k1 at chz_pos1(t, k1): lane i wants 4 t + k1 = i + 64 r, i.e. t = (i >> 2) + 16 r, k1 = i & 3
+    const cf2 *src = A + chz_pos1(lane >> 2, k);
 #pragma unroll
-        for (int r = 0; r < 16; r++) u[r] = src[16 * r];
-    } else {
-        const cf2 *src = A + cpad(lane);                        // cpad(lane + 64 r) = cpad(lane) + 68 r
-#pragma unroll
-        for (int r = 0; r < 16; r++) u[r] = src[68 * r];
-    }
-    if constexpr (REGS) {
-        // 12-wave kernel: the fold waves have already applied the input twiddles W_64^{r k} (chz_fold2_ring).  (Read from the
-        // LDS table here, one pair at a time between the multiplies, they cost eight exposed LDS latencies per pass: measured
-        // with s_memtime, pass 2 took 2950 cycles per frame against 1780 for pass 3.)
-        (void)twr;
-    } else {
-        // The 15 twiddles are loop invariant; hoisted out of the batch loop they would pin 30 VGPRs the 4-wave kernel does
-        // not have.  The empty asm hides the invariance of the index (laundering the POINTER instead turns the reads
-        // into flat loads); re-reading 120 B of LDS per batch is free.
-        int kk = k;
-        asm volatile("" : "+v"(kk));
-#pragma unroll
-        for (int r = 1; r < 16; r++) u[r] = cmul(u[r], tab[4 * r + kk]);
-    }
+    for (int r = 0; r < 16; r++) u[r] = src[16 * r];
     // DFT16 = 4 x DFT4 over a (s = 4a + b), twiddle W16^{bc}, 4 x DFT4 over b -> X[c + 4d]
     cf2 v[4][4];
 #pragma unroll
@@ -288,83 +197,48 @@ __device__ __forceinline__ void chz_p2_t(cf2 *A, const cf2 *tab, const cf2 (&twr
     v[3][2] = cmul_s(v[3][2], (cf2){ -R2, -R2 });               // W16^6
     v[3][3] = cmul_s(v[3][3], (cf2){ -C1, S1 });                // W16^9
     // all reads of this wave precede its writes in program order; nobody else touches this frame during pass 2
-    if constexpr (REGS) {
-        cf2 *dst = A + 17 * (lane - k) + k;                     // chz_pos2(16 (i-k) + k + 4 r) = 17 (i-k) + k + 4 r   (k + 4 r < 64)
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            cf2 X[4];
-            dft4(v[0][c], v[1][c], v[2][c], v[3][c], X);
-#pragma unroll
-            for (int d = 0; d < 4; d++) dst[4 * (c + 4 * d)] = X[d];
-        }
-    } else {
-    cf2 *dst = A + 17 * (lane - k) + k;                         // cpad(16 (i-k) + k + 4 r) = 17 (i-k) + k + 4 r + (r >> 2)
+    cf2 *dst = A + 17 * (lane - k) + k;                         // chz_pos2(16 (i-k) + k + 4 r) = 17 (i-k) + k + 4 r   (k + 4 r < 64)
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         cf2 X[4];
         dft4(v[0][c], v[1][c], v[2][c], v[3][c], X);
 #pragma unroll
-        for (int d = 0; d < 4; d++) dst[4 * (c + 4 * d) + d] = X[d];   // r = c + 4 d, (r >> 2) = d
-    }
-    }
-}
-
-__device__ __forceinline__ void chz_p2(cf2 *A, const cf2 *tab, int lane)
-{
-    const cf2 none[15] = {};
-    chz_p2_t<false>(A, tab, none, lane);
-}
-
-// pass 3, radix 4, p = 64: u[r] = B[t + 256 r] e^{-2 pi i r k / 256}, k = t & 63; C[4 (t - k) + k + 64 r] = X[r]
-// The four frames of a batch are independent: all sixteen LDS reads are issued before the first butterfly (the compiler
-// otherwise keeps read -> wait -> butterfly per frame, four exposed LDS latencies per pass).
-__device__ __forceinline__ void chz_p3_batch(const cf2 *A, cf2 *Cb, const cf2 (&tw)[3], int t)
-{
-    const cf2 *src = A + cpad(t);                               // cpad(t + 256 r) = cpad(t) + 272 r
-    cf2 u[CHZ_BATCH][4];
-#pragma unroll
-    for (int g = 0; g < CHZ_BATCH; g++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) u[g][r] = src[g * CHZ_FB + 272 * r];
-    const int k = t & 63;
-    cf2 *d = Cb + cpad(4 * (t - k) + k);                        // cpad(j + 64 r) = cpad(j) + 68 r
-#pragma unroll
-    for (int g = 0; g < CHZ_BATCH; g++) {
-        cf2 o[4];
-        dft4(u[g][0], cmul(u[g][1], tw[0]), cmul(u[g][2], tw[1]), cmul(u[g][3], tw[2]), o);
-        d[g * CHZ_FB] = o[0]; d[g * CHZ_FB + 68] = o[1]; d[g * CHZ_FB + 136] = o[2]; d[g * CHZ_FB + 204] = o[3];
+        for (int d = 0; d < 4; d++) dst[4 * (c + 4 * d)] = X[d];
     }
 }
 
-// pass 4, radix 4, p = 256: bins t + 256 r of the frame; `u` = the frame's four inputs (read by chz_p4_load)
-__device__ __forceinline__ void chz_p4_load(const cf2 *Cb, int t, cf2 (&u)[CHZ_BATCH][4])
+// pass 3 of the 4 x 16 x 16 factorisation, radix 16, p = 64, one frame per wave:
+//   lane i: u[r] = A[i + 64 r] W_1024^{r i};  bin i + 64 q = DFT16(u)[q]   (natural order, planar layout over the same buffer:
+//   every output depends on all sixteen inputs, so the reads have returned before the first store is issued)
+__device__ __forceinline__ void chz_p3(cf2 *A, const cf2 (&tw)[15], int lane)
 {
-    const cf2 *src = Cb + cpad(t);
+    cf2 u[16];
+    const cf2 *src = A + lane;                                  // chz_pos2(lane + 64 r) = lane + 68 r
 #pragma unroll
-    for (int g = 0; g < CHZ_BATCH; g++)
+    for (int r = 0; r < 16; r++) u[r] = src[68 * r];
 #pragma unroll
-        for (int r = 0; r < 4; r++) u[g][r] = src[g * CHZ_FB + 272 * r];
-}
-__device__ __forceinline__ void chz_p4(const cf2 (&u)[4], const cf2 (&tw)[3], cf2 (&y)[4])
-{
-    dft4(u[0], cmul(u[1], tw[0]), cmul(u[2], tw[1]), cmul(u[3], tw[2]), y);
-}
-
-// per-thread constants of the pipeline
-template <int P> struct ChzRegs {
-    cf2 coef[4][P / 2];      // (h[t + 256 j + qM], h[t + 256 j + (q+1)M]), q even
-    cf2 tw3[3], tw4[3];      // pass 3 / pass 4 twiddles
-};
-template <int P>
-__device__ __forceinline__ void chz_setup(ChzRegs<P> &R, const float *taps, cf2 *tab, int t)
-{
+    for (int r = 1; r < 16; r++) u[r] = cmul(u[r], tw[r - 1]);
+    cf2 v[4][4];
 #pragma unroll
-    for (int j = 0; j < 4; j++)
+    for (int b = 0; b < 4; b++) dft4(u[b], u[4 + b], u[8 + b], u[12 + b], v[b]);
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
+    v[1][1] = cmul_s(v[1][1], (cf2){ C1, -S1 });
+    v[1][2] = cmul_s(v[1][2], (cf2){ R2, -R2 });
+    v[1][3] = cmul_s(v[1][3], (cf2){ S1, -C1 });
+    v[2][1] = cmul_s(v[2][1], (cf2){ R2, -R2 });
+    v[2][2] = mul_mi(v[2][2]);
+    v[2][3] = cmul_s(v[2][3], (cf2){ -R2, -R2 });
+    v[3][1] = cmul_s(v[3][1], (cf2){ S1, -C1 });
+    v[3][2] = cmul_s(v[3][2], (cf2){ -R2, -R2 });
+    v[3][3] = cmul_s(v[3][3], (cf2){ -C1, S1 });
+    float *dst = (float *)A + lane;                             // chz_planar(lane + 64 q) = chz_planar(64 q) + lane
 #pragma unroll
-        for (int q = 0; q < P; q += 2) R.coef[j][q / 2] = (cf2){ taps[t + 256 * j + q * CHZ_M], taps[t + 256 * j + (q + 1) * CHZ_M] };
+    for (int c = 0; c < 4; c++) {
+        cf2 X[4];
+        dft4(v[0][c], v[1][c], v[2][c], v[3][c], X);
 #pragma unroll
-    for (int r = 1; r < 4; r++) { R.tw3[r - 1] = chz_twiddle(r * (t & 63), 256); R.tw4[r - 1] = chz_twiddle(r * t, 1024); }
-    if (t < 64) tab[t] = chz_twiddle((t >> 2) * (t & 3), 64);   // tab[4 r + k]
+        for (int d = 0; d < 4; d++) { dst[chz_planar(64 * (c + 4 * d))] = X[d].x; dst[chz_planar(64 * (c + 4 * d)) + 128] = X[d].y; }
+    }
 }
 
 // Input samples of launch-relative frame F for this thread: virtual indices F*D + t and F*D + 256 + t.  A batch that
@@ -402,247 +276,11 @@ struct ChzIn {
     }
 };
 
-template <int P>
-__global__ __launch_bounds__(256) void chz_pfb_fft_kernel(ChzArgs a)
-{
-    constexpr int M = CHZ_M, D = CHZ_D;
-    __shared__ cf2 bufA[CHZ_BATCH * CHZ_FB];
-    __shared__ cf2 bufC[CHZ_BATCH * CHZ_FB];
-    __shared__ cf2 tab[64];
-    const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
-    const uint32_t f0 = blockIdx.x * a.frames_per_wg;          // first frame of this workgroup (launch-relative, multiple of 8)
-    if (f0 >= a.nframes) return;
-    uint32_t f1 = f0 + a.frames_per_wg; if (f1 > a.nframes) f1 = a.nframes;
-
-    // virtual input stream of this launch: index v in [-(L-D), nsamp + leftover): carry then block.
-    // frame f (launch-relative) consumes v in [f*D - (L-D), f*D + D); the absolute frame index of f = 0 is even
-    // (the host only ever consumes an even number of frames), so parity(m) = parity(f) and residue(v) = v mod M.
-    const ChzIn in{ a.block, a.carry, (int64_t)a.hist, (int64_t)a.carry_len - (int64_t)a.hist, (int64_t)a.carry_len, (int64_t)a.nsamp };
-    ChzRegs<P> R;
-    chz_setup<P>(R, a.taps, tab, t);
-    // delay lines: branch jb (residue r = t + 256 jb) holds its P most recent samples before frame f0:
-    // v_last = largest v < f0*D with v mod M == r   (f0*D is a multiple of M because f0 is even)
-    cf2 line[4][P];
-    {
-        const int64_t vend = (int64_t)f0 * D;
-#pragma unroll
-        for (int jb = 0; jb < 4; jb++) {
-            const int64_t vlast = vend - M + (t + 256 * jb);
-#pragma unroll
-            for (int q = 0; q < P; q++) line[jb][q] = in.generic(vlast - (int64_t)M * (P - 1 - q));
-        }
-    }
-    __syncthreads();                                             // tab
-
-    // eight frames (two batches) of this thread's four bins stay in registers and leave as 64-byte runs of the
-    // channel-major output.  Frames past f1 (a partial last group) run on zero padding and are not stored.
-    for (uint32_t fg = f0; fg < f1; fg += CHZ_GROUP) {
-        cf2 acc[CHZ_GROUP][4];
-        const int ng = (int)(f1 - fg < (uint32_t)CHZ_GROUP ? f1 - fg : (uint32_t)CHZ_GROUP);
-#pragma unroll
-        for (int hb = 0; hb < CHZ_GROUP; hb += CHZ_BATCH) {
-            auto fold4 = [&](auto fastc) {
-                cf2 nx[CHZ_BATCH][2];
-#pragma unroll
-                for (int g = 0; g < CHZ_BATCH; g++) in.template frame<decltype(fastc)::value>((int64_t)fg + hb + g, t, nx[g][0], nx[g][1]);
-                chz_fold_batch<P>(line, R.coef, nx, bufA, t);
-            };
-            if (in.batch_in_block((int64_t)fg + hb)) fold4(std::true_type{}); else fold4(std::false_type{});
-            __syncthreads();
-            chz_p2(bufA + wv * CHZ_FB, tab, lane);
-            __syncthreads();
-            chz_p3_batch(bufA, bufC, R.tw3, t);
-            __syncthreads();
-            {
-                cf2 u4[CHZ_BATCH][4];
-                chz_p4_load(bufC, t, u4);
-#pragma unroll
-                for (int g = 0; g < CHZ_BATCH; g++) chz_p4(u4[g], R.tw4, acc[hb + g]);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t ch = ((uint32_t)(t + 256 * j) - a.first_bin) & (M - 1);
-            if (ch < a.n_channels) {
-                float2 *dstp = a.out + (uint64_t)ch * a.ld + fg;
-                if (ng == CHZ_GROUP) {
-#pragma unroll
-                    for (int e = 0; e < CHZ_GROUP; e += 2)
-                        *(float4 *)(dstp + e) = make_float4(acc[e][j].x, acc[e][j].y, acc[e + 1][j].x, acc[e + 1][j].y);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < CHZ_GROUP; e++)
-                        if (e < ng) dstp[e] = make_float2(acc[e][j].x, acc[e][j].y);
-                }
-            }
-        }
-    }
-}
-
-// ---- fused form: channelizer + FM discriminator + boxcar + slicer; only 1 bit per channel sample reaches HBM ----
-// After the FFT a lane owns bins {t, t+256, t+512, t+768} in every frame, so the per-channel stream state of the
-// RECC front end is four small register sets: previous frame's value, the last two demod floats (boxcar over
-// 3 samples per symbol, ordered aligned-pair sums of include/amps_recc_numerics.h) and a 32-bit slicer shift
-// register that is stored to the channel's bit ring every 32 frames.  The arithmetic is the same as
-// recc_front_kernel's on the channel-major intermediate, so both forms produce identical bits.
-template <int PAR, bool FOUR = true>
-__device__ __forceinline__ void chz_bins(const cf2 (&y)[4], cf2 (&prev)[4], f2 (&d1)[2], f2 (&d2)[2], uint32_t (&gw)[4])
-{
-    f2 d[2];
-    if constexpr (FOUR) fm_phase_four(y, prev, d[0], d[1]);       // two chains in lock step (same bits, fewer stalls, more registers)
-    else { d[0] = fm_phase_two(y[0], prev[0], y[1], prev[1]); d[1] = fm_phase_two(y[2], prev[2], y[3], prev[3]); }
-#pragma unroll
-    for (int h = 0; h < 2; h++) {                                 // bins (0,1) and (2,3): the boxcar adds are packed per pair
-        // window [n-2, n]: n even -> (d[n-2] + d[n-1]) + d[n];  n odd -> d[n-2] + (d[n-1] + d[n])
-        const f2 s = PAR == 0 ? (d2[h] + d1[h]) + d[h] : d2[h] + (d1[h] + d[h]);
-        // gw = (gw >> 1) | (s >= 0) << 31 as one v_alignbit per bin
-        gw[2 * h] = __builtin_amdgcn_alignbit(s.x >= 0.0f ? 1u : 0u, gw[2 * h], 1);
-        gw[2 * h + 1] = __builtin_amdgcn_alignbit(s.y >= 0.0f ? 1u : 0u, gw[2 * h + 1], 1);
-        d2[h] = d1[h]; d1[h] = d[h];
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) prev[j] = y[j];
-}
-
-// Slicer spec B (include/amps_recc_numerics.h): g = !signbit(yi * pr - yr * pi) with p = the same bin three frames (one
-// Manchester symbol) earlier.  One v_pk_mul (the partner's halves swapped by op_sel), one v_sub and one v_alignbit per bin:
-// the register collects SIGN bits, newest at bit 0, and is bit-reversed and inverted when it is stored.
-__device__ __forceinline__ void chz_slice_prod(const cf2 (&y)[4], const cf2 (&p)[4], uint32_t (&gw)[4])
-{
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        cf2 m;                                                    // (yr * pi, yi * pr) = (b, a): the partner's halves swapped by op_sel
-        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(m) : "v"(y[j]), "v"(p[j]));
-        const float sdiff = m.y - m.x;
-        gw[j] = __builtin_amdgcn_alignbit(gw[j], __float_as_uint(sdiff), 31);   // (gw << 1) | signbit
-    }
-}
-
-// Slicer spec C: d' = Im(y conj(prev)) = fmaf(yi, pr, -(yr * pi)) (the `im` of spec A's conj-product, no arctangent), spec A's
-// 3-sample boxcar in its aligned-pair order, g = !signbit(S').  Sign bits are collected like spec B's.
-template <int PAR>
-__device__ __forceinline__ void chz_bins_sine(const cf2 (&y)[4], cf2 (&prev)[4], f2 (&d1)[2], f2 (&d2)[2], uint32_t (&gw)[4])
-{
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        const cf2 y0 = y[2 * h], p0 = prev[2 * h], y1 = y[2 * h + 1], p1 = prev[2 * h + 1];
-        const f2 d = { __builtin_fmaf(y0.y, p0.x, -(y0.x * p0.y)), __builtin_fmaf(y1.y, p1.x, -(y1.x * p1.y)) };
-        const f2 s = PAR == 0 ? (d2[h] + d1[h]) + d : d2[h] + (d1[h] + d);
-        gw[2 * h] = __builtin_amdgcn_alignbit(gw[2 * h], __float_as_uint(s.x), 31);
-        gw[2 * h + 1] = __builtin_amdgcn_alignbit(gw[2 * h + 1], __float_as_uint(s.y), 31);
-        d2[h] = d1[h]; d1[h] = d;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) prev[j] = y[j];
-}
-
-// P = 8 is held to 256 VGPRs = two waves per SIMD (left alone the allocator takes 258 and halves the occupancy;
-// __launch_bounds__(256, 3) would force 168 and spill: 2.9 ms instead of 1.0).  P = 16 needs ~390: one wave per SIMD.
-template <int P, int SL = AMPS_SLICER_ATAN_BOXCAR>
-__global__ __launch_bounds__(256, P <= 8 ? 2 : 1) void chz_fused_kernel(ChzArgs a)
-{
-    constexpr int M = CHZ_M, D = CHZ_D;
-    __shared__ cf2 bufA[CHZ_BATCH * CHZ_FB];
-    __shared__ cf2 bufC[CHZ_BATCH * CHZ_FB];
-    __shared__ cf2 tab[64];
-    const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
-    const int64_t f0 = (int64_t)blockIdx.x * a.frames_per_wg;   // multiple of 64
-    if (f0 >= (int64_t)a.nframes) return;
-    int64_t f1 = f0 + a.frames_per_wg; if (f1 > (int64_t)a.nframes) f1 = a.nframes;
-    const int64_t fs = f0 - CHZ_PRE;                             // pre-roll (one batch): rebuild prev / d1 / d2 of every bin
-
-    const ChzIn in{ a.block, a.carry, (int64_t)a.hist, (int64_t)a.carry_len - (int64_t)a.hist, (int64_t)a.carry_len, (int64_t)a.nsamp };
-    ChzRegs<P> R;
-    chz_setup<P>(R, a.taps, tab, t);
-    cf2 line[4][P];
-    {
-        const int64_t vend = fs * D;                              // multiple of M (fs is even)
-#pragma unroll
-        for (int jb = 0; jb < 4; jb++) {
-            const int64_t vlast = vend - M + (t + 256 * jb);
-#pragma unroll
-            for (int q = 0; q < P; q++) line[jb][q] = in.generic(vlast - (int64_t)M * (P - 1 - q));
-        }
-    }
-    cf2 prev[4] = {};
-    f2 d1[2] = {}, d2[2] = {};                                    // the last two demod floats of bins (0,1) and (2,3)
-    cf2 hist[3][4] = {};                                          // spec B: this lane's bins in frames 1..3 of the previous batch
-    uint32_t gw[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) gw[j] = SL != AMPS_SLICER_ATAN_BOXCAR ? 0u : ~0u;   // "ones before the stream" in either representation
-    const uint64_t mask32 = 2ull * a.ring_words - 1;
-
-    // the inputs of a whole batch are loaded one batch (~7 us) ahead
-    cf2 nx[CHZ_BATCH][2];
-#pragma unroll
-    for (int g = 0; g < CHZ_BATCH; g++) in.template frame<false>(fs + g, t, nx[g][0], nx[g][1]);
-    __syncthreads();                                             // tab
-
-    for (int64_t f = fs; f < f1; f += CHZ_BATCH) {               // fs and f1 are multiples of 4
-        auto fold4 = [&](auto fastc) {                           // fold this batch, then load the next one (a batch ahead)
-            chz_fold_batch<P>(line, R.coef, nx, bufA, t);
-#pragma unroll
-            for (int g = 0; g < CHZ_BATCH; g++)
-                in.template frame<decltype(fastc)::value>(f + CHZ_BATCH + g, t, nx[g][0], nx[g][1]);   // generic: zero beyond the data
-        };
-        if (in.batch_in_block(f + CHZ_BATCH)) fold4(std::true_type{}); else fold4(std::false_type{});
-        __syncthreads();
-        chz_p2(bufA + wv * CHZ_FB, tab, lane);
-        __syncthreads();
-        chz_p3_batch(bufA, bufC, R.tw3, t);
-        __syncthreads();
-        cf2 u4[CHZ_BATCH][4];
-        chz_p4_load(bufC, t, u4);
-        if constexpr (SL == AMPS_SLICER_PRODUCT) {
-            // frame g pairs with frame g - 3: frames 0..2 with frames 1..3 of the previous batch, frame 3 with frame 0
-            cf2 y0[4];
-            chz_p4(u4[0], R.tw4, y0);
-            chz_slice_prod(y0, hist[0], gw);
-            chz_p4(u4[1], R.tw4, hist[0]);                        // frame 1 takes the place of the value it replaces
-            chz_slice_prod(hist[0], hist[1], gw);
-            chz_p4(u4[2], R.tw4, hist[1]);
-            chz_slice_prod(hist[1], hist[2], gw);
-            chz_p4(u4[3], R.tw4, hist[2]);
-            chz_slice_prod(hist[2], y0, gw);
-        } else if constexpr (SL == AMPS_SLICER_SINE) {
-#pragma unroll
-            for (int g = 0; g < CHZ_BATCH; g++) {
-                cf2 y[4];
-                chz_p4(u4[g], R.tw4, y);
-                if (g & 1) chz_bins_sine<1>(y, prev, d1, d2, gw); else chz_bins_sine<0>(y, prev, d1, d2, gw);
-            }
-            if (a.stream_start && f < 0) {                        // frames before the stream are exactly +0 (the FFT of zeros may hold -0):
-                asm volatile("" ::: "memory");                    // the state they leave is all zeros (a real branch, once per launch)
-#pragma unroll
-                for (int j = 0; j < 4; j++) { prev[j] = (cf2){ 0.f, 0.f }; gw[j] = 0u; }
-                d1[0] = d1[1] = d2[0] = d2[1] = (f2){ 0.f, 0.f };
-            }
-        } else {
-#pragma unroll
-        for (int g = 0; g < CHZ_BATCH; g++) {
-            cf2 y[4];
-            chz_p4(u4[g], R.tw4, y);
-            if (g & 1) chz_bins<1>(y, prev, d1, d2, gw); else chz_bins<0>(y, prev, d1, d2, gw);
-        }
-        }
-        if (f >= f0 && ((f + 3) & 31) == 31) {                    // 32 real frames collected (f0 is a multiple of 64)
-            const uint64_t n = a.n_done + (uint64_t)(f + 3);      // absolute index of the newest bit
-#pragma unroll
-            for (int j = 0; j < 4; j++) {                         // channel / ring address recomputed here: 12 fewer live VGPRs
-                const uint32_t ch = ((uint32_t)(t + 256 * j) - a.first_bin) & (M - 1);
-                uint32_t word = SL != AMPS_SLICER_ATAN_BOXCAR ? ~__builtin_bitreverse32(gw[j]) : gw[j];
-                if (SL == AMPS_SLICER_PRODUCT && a.stream_start && f + 3 == 31) word |= 7u;   // no partner yet: g = 1
-                if (ch < a.n_channels) ((uint32_t *)(a.gring + (uint64_t)ch * a.ring_words))[(n >> 5) & mask32] = word;
-            }
-        }
-    }
-}
-
-// The delay lines as a register RING (12-wave kernel): branch jb keeps P + 4 slots; at a half-step with rotation BASE the
+// The delay lines as a register RING: branch jb keeps P + 4 slots; at a half-step with rotation BASE the
 // logical element i of the old {delay line, new samples} view is ring[jb][(BASE + i) % (P + 4)]: elements 0..P-1 the delay
 // line, P and P+1 the samples of this half-step's four frames, P+2 and P+3 those of the NEXT half-step (in flight).  After
 // the fold the two oldest slots are dead and receive the loads of the half-step after next, and BASE advances by two: no
-// register ever moves (the 4-wave kernels shift 32 register pairs per four frames), and a load has two half-steps to land.
+// register ever moves (round 1 shifted 32 register pairs per four frames), and a load has two half-steps to land.
 // The half-step loop is unrolled over the ring's period of (P + 4) / 2 rotations.
 //
 // Two frames at a time: eight independent accumulator chains (2 frames x 4 branches), two taps per asm block.  Measured
@@ -758,88 +396,56 @@ __device__ __forceinline__ void chz_ring_wait(cf2 (&ring)[4][P + 4])
                       "+v"(ring[0][(BASE + P + 1) % R]), "+v"(ring[1][(BASE + P + 1) % R]), "+v"(ring[2][(BASE + P + 1) % R]), "+v"(ring[3][(BASE + P + 1) % R]));
 }
 
-// ---- the 12-wave pipeline (P = 8): fold waves and FFT waves ----
-// The 4-wave kernels above keep every per-thread state of the filter bank in ONE set of waves: delay lines, coefficients and
-// input prefetch (112 VGPRs) next to the radix-16 temporaries (64) and the twiddles -- 222 VGPRs, two waves per SIMD, and a
-// 70 KB exchange buffer per workgroup; half of the issue slots stay empty while both waves of a SIMD sit in LDS latency or in
-// one of the three barriers per four frames.  Here one 768-thread workgroup owns a CU and splits the ROLES between waves:
-//   waves 0..3   "fold":  thread t keeps branches t + 256 j in registers (exactly as above), folds a frame and runs the
-//                radix-4 pass 1 on its own registers -> bufA[next][frame].  Pure VALU + prefetched global loads.
-//   waves 4..11  "FFT":   wave w owns frame w of a batch of EIGHT outright and runs the rest of the FFT wave-privately, in
-//                place: pass 2 (radix 16, p = 4) as above, then ONE more radix-16 pass (p = 64: lane i takes points
-//                i + 64 r, twiddles W_1024^{r i} from registers) which leaves the frame in natural order.  After a barrier
-//                thread u reads bins u and u + 512 of all eight frames: a lane owns the same two channels for ever, and
-//                the slicer state is two small register sets.
-// The fold waves work one batch ahead into the other half of a double buffer (2 x 8 frames = 136 KB of LDS), so a batch
-// costs two workgroup barriers per EIGHT frames instead of six, the fold's VALU stream fills the issue slots the FFT waves
-// leave while they wait for LDS, and both roles fit 168 VGPRs: three waves per SIMD.  FFT-1024 = 4 x 16 x 16 needs one
-// LDS round trip less than 4 x 16 x 4 x 4.  The unfused form is the same kernel with a different epilogue (MODE_IQ: the
-// bins go to the channel-major block as 64-byte runs), so fused and unfused forms stay bit-identical by construction.
-constexpr int CHZ_NB = 8;                                        // frames per batch
+
+// ---- the three-role pipeline ----
+// Round 2's kernel had two roles (4 fold waves, 8 FFT waves that also ran the slicer): the eight FFT waves moved in lock step
+// -- all reading LDS, all computing, all writing -- so LDS bursts and VALU bursts alternated instead of overlapping, two FFT
+// waves in the same phase shared every SIMD, and the slicer sat on their critical path behind a second barrier (VALU issue
+// slots 0.57 busy, waves parked 39 % of their cycles).  Here a time step is FOUR frames and every SIMD holds three waves in
+// three different phases:
+//   waves 0..3  "fold"  : thread t keeps branches t + 256 j as a register ring, folds the four frames of half-batch h and runs
+//                         the radix-4 pass 1 (+ pass 2's input twiddles) on its own registers -> slot h & 3.  Pure VALU +
+//                         prefetched global loads.
+//   waves 4..7  "pass 2": wave w transforms frame w of half-batch h - 1 (radix 16, p = 4), in place.
+//   waves 8..11 "pass 3": wave w first slices half-batch h - 3 (all four frames, four channels per lane, planar operands),
+//                         then transforms frame w of half-batch h - 2 (radix 16, p = 64) into the planar layout.
+// ONE workgroup barrier per four frames (round 2: two per eight, with the slicer between them).  A half-batch lives four time
+// steps in a four-slot ring of 4 x 4 frame buffers = 136 KB of LDS; every role stays below 168 VGPRs: three waves per SIMD.
+// The unfused form is the same kernel with a different epilogue (MODE = CHZ12_IQ: the bins leave as 32-byte runs of the
+// channel-major block), so fused and unfused forms stay bit-identical by construction.
+constexpr int CHZ_SLOTS = 4;                                     // half-batches in flight
+constexpr int CHZ_PREROLL = 8;                                   // frames re-run in front of a workgroup's range (two half-batches)
 constexpr int CHZ12_IQ = -1;                                     // MODE: write the channel-major block; >= 0: AMPS_SLICER_* fused behind the FFT
 
-// pass 3 of the 4 x 16 x 16 factorisation, radix 16, p = 64, one frame per wave, in place:
-//   lane i: u[r] = A[i + 64 r] W_1024^{r i};  A[i + 64 r] = DFT16(u)[r]        (natural bin order)
-__device__ __forceinline__ void chz_p34(cf2 *A, const cf2 (&tw)[15], int lane)
-{
-    cf2 u[16];
-    cf2 *src = A + lane;                                        // chz_pos2(lane + 64 r) = lane + 68 r
-#pragma unroll
-    for (int r = 0; r < 16; r++) u[r] = src[68 * r];
-#pragma unroll
-    for (int r = 1; r < 16; r++) u[r] = cmul(u[r], tw[r - 1]);
-    cf2 v[4][4];
-#pragma unroll
-    for (int b = 0; b < 4; b++) dft4(u[b], u[4 + b], u[8 + b], u[12 + b], v[b]);
-    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
-    v[1][1] = cmul_s(v[1][1], (cf2){ C1, -S1 });
-    v[1][2] = cmul_s(v[1][2], (cf2){ R2, -R2 });
-    v[1][3] = cmul_s(v[1][3], (cf2){ S1, -C1 });
-    v[2][1] = cmul_s(v[2][1], (cf2){ R2, -R2 });
-    v[2][2] = mul_mi(v[2][2]);
-    v[2][3] = cmul_s(v[2][3], (cf2){ -R2, -R2 });
-    v[3][1] = cmul_s(v[3][1], (cf2){ S1, -C1 });
-    v[3][2] = cmul_s(v[3][2], (cf2){ -R2, -R2 });
-    v[3][3] = cmul_s(v[3][3], (cf2){ -C1, S1 });
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-        cf2 X[4];
-        dft4(v[0][c], v[1][c], v[2][c], v[3][c], X);
-#pragma unroll
-        for (int d = 0; d < 4; d++) src[68 * (c + 4 * d)] = X[d];
-    }
-}
-
-// slicer state of the two bins a lane of the FFT role owns (specs of include/amps_recc_numerics.h)
-template <int SL> struct ChzSlice2 {
-    cf2 prev[2];             // spec A / C: the bins one frame earlier
-    f2 d1, d2;               // spec A / C: the last two discriminator outputs of (bin 0, bin 1)
-    cf2 h1[2], h2[2], h3[2]; // spec B: the bins one, two and three frames earlier
+// Slicer state of TWO channels of one lane, planar (.x = the first channel, .y = the second): the specs of
+// include/amps_recc_numerics.h, operation by operation, two channels per packed instruction.
+template <int SL> struct ChzSlicePair {
+    f2 pr, pi;               // spec A / C: the bins one frame earlier
+    f2 d1, d2;               // spec A / C: the last two discriminator outputs
+    f2 h1r, h1i, h2r, h2i, h3r, h3i;   // spec B: the bins one, two and three frames earlier
     uint32_t gw[2];          // spec A: slicer bits, newest at bit 31; specs B / C: SIGN bits, newest at bit 0
     __device__ __forceinline__ void reset()
     {
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            prev[j] = h1[j] = h2[j] = h3[j] = (cf2){ 0.f, 0.f };
-            gw[j] = SL == AMPS_SLICER_ATAN_BOXCAR ? ~0u : 0u;     // "ones before the stream" in either representation
-        }
-        d1 = d2 = (f2){ 0.f, 0.f };
+        const f2 z = { 0.f, 0.f };
+        pr = pi = d1 = d2 = h1r = h1i = h2r = h2i = h3r = h3i = z;
+        gw[0] = gw[1] = SL == AMPS_SLICER_ATAN_BOXCAR ? ~0u : 0u;     // "ones before the stream" in either representation
     }
-    template <int PAR> __device__ __forceinline__ void step(const cf2 (&y)[2])   // PAR = parity of the absolute frame index
+    template <int PAR> __device__ __forceinline__ void step(f2 yr, f2 yi)   // PAR = parity of the absolute frame index
     {
         if constexpr (SL == AMPS_SLICER_PRODUCT) {
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                cf2 m;                                              // (yr * pi, yi * pr): the partner's halves swapped by op_sel
-                asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(m) : "v"(y[j]), "v"(h3[j]));
-                gw[j] = __builtin_amdgcn_alignbit(gw[j], __float_as_uint(m.y - m.x), 31);
-                h3[j] = h2[j]; h2[j] = h1[j]; h1[j] = y[j];
-            }
+            // g = !signbit(yi * pr3 - yr * pi3), the partner three frames (one Manchester symbol) earlier
+            const f2 sd = yi * h3r - yr * h3i;
+            gw[0] = __builtin_amdgcn_alignbit(gw[0], __float_as_uint(sd.x), 31);
+            gw[1] = __builtin_amdgcn_alignbit(gw[1], __float_as_uint(sd.y), 31);
+            h3r = h2r; h3i = h2i; h2r = h1r; h2i = h1i; h1r = yr; h1i = yi;
         } else {
             f2 d;
-            if constexpr (SL == AMPS_SLICER_SINE)
-                d = (f2){ __builtin_fmaf(y[0].y, prev[0].x, -(y[0].x * prev[0].y)), __builtin_fmaf(y[1].y, prev[1].x, -(y[1].x * prev[1].y)) };
-            else d = fm_phase_two(y[0], prev[0], y[1], prev[1]);
+            if constexpr (SL == AMPS_SLICER_SINE) d = __builtin_elementwise_fma(yi, pr, -(yr * pi));     // Im(y conj(prev))
+            else {
+                const f2 re = __builtin_elementwise_fma(yr, pr, yi * pi);                                 // y conj(prev)
+                const f2 im = __builtin_elementwise_fma(yi, pr, -(yr * pi));
+                d = fm_phase_planar(re, im);
+            }
             // window [n-2, n]: n even -> (d[n-2] + d[n-1]) + d[n];  n odd -> d[n-2] + (d[n-1] + d[n])
             const f2 s = PAR == 0 ? (d2 + d1) + d : d2 + (d1 + d);
             if constexpr (SL == AMPS_SLICER_SINE) {
@@ -850,32 +456,31 @@ template <int SL> struct ChzSlice2 {
                 gw[1] = __builtin_amdgcn_alignbit(s.y >= 0.0f ? 1u : 0u, gw[1], 1);
             }
             d2 = d1; d1 = d;
-            prev[0] = y[0]; prev[1] = y[1];
+            pr = yr; pi = yi;
         }
     }
-    __device__ __forceinline__ uint32_t word(int j) const { return SL == AMPS_SLICER_ATAN_BOXCAR ? gw[j] : ~__builtin_bitreverse32(gw[j]); }
+    __device__ __forceinline__ uint32_t word(int e) const { return SL == AMPS_SLICER_ATAN_BOXCAR ? gw[e] : ~__builtin_bitreverse32(gw[e]); }
 };
 
 template <int P, int MODE>
 __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
 {
-    constexpr int M = CHZ_M, D = CHZ_D, NB = CHZ_NB;
+    constexpr int M = CHZ_M, D = CHZ_D, NB = CHZ_BATCH;
     constexpr bool IQ = MODE == CHZ12_IQ;
     constexpr int SL = IQ ? AMPS_SLICER_ATAN_BOXCAR : MODE;
-    __shared__ cf2 bufA[2][NB * CHZ_FB];
+    __shared__ cf2 buf[CHZ_SLOTS * NB * CHZ_FB];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int64_t f0 = (int64_t)blockIdx.x * a.frames_per_wg;   // multiple of 64
     if (f0 >= (int64_t)a.nframes) return;
     int64_t f1 = f0 + a.frames_per_wg; if (f1 > (int64_t)a.nframes) f1 = a.nframes;
-    // the slicer state of every bin is rebuilt by one pre-roll batch; its first four frames may reach behind the carry
-    // (zeros): they only prime the delay lines for the last four, which are exact (the carry holds L - D + 4 D samples)
-    const int64_t fs = IQ ? f0 : f0 - NB;
-    const int nbatch = (int)((f1 - fs + NB - 1) / NB);
+    // the slicer state of every bin is rebuilt by two pre-roll half-batches; the first may reach behind the carry (zeros): it
+    // only primes the delay lines for the second, which is exact (the carry holds L - D + 4 D samples)
+    const int64_t fs = IQ ? f0 : f0 - CHZ_PREROLL;
+    const int nh = (int)((f1 - fs + NB - 1) / NB);              // half-batches of this workgroup
+    const int nsteps = nh + 3;                                    // time step i: fold h = i, pass 2 h = i - 1, pass 3 h = i - 2, slicer h = i - 3
 
-    // time step s: the fold waves produce batch s into bufA[s & 1] while the FFT waves consume batch s - 1 from the other
-    // half; both roles pass the same two barriers per step
     if (wave < 4) {
         // ------------------------------------------------------------------ fold role
         const int t = tid;
@@ -899,90 +504,114 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
             }
         }
         chz_load_half_ring<P, 0, P, false>(ring, in, fs, t);
-        chz_load_half_ring<P, 0, P + 2, false>(ring, in, fs + CHZ_BATCH, t);
-        __syncthreads();                                          // both roles start together
+        chz_load_half_ring<P, 0, P + 2, false>(ring, in, fs + NB, t);
+        __syncthreads();                                          // all roles start together
         // one half-step = four frames: fold them, then load the frames of the half-step after next into the two slots that
-        // just died.  A load has eight frames (~4 us) to arrive: with four frames of lead, as in the 4-wave kernels, the fold
-        // waves were the critical path (4 waves x 8 loads x 512 B = 16 KB in flight per CU do not cover the HBM latency under
-        // load: fold + slicer alone ran 0.39 ms per GiB, the FFT waves alone 0.31).
-        auto half_step = [&](auto basec, int sidx, int half) {
+        // just died.  A load has eight frames (~3 us) to arrive: with four frames of lead the fold waves were the critical path
+        // (4 waves x 8 loads x 512 B = 16 KB in flight per CU do not cover the HBM latency under load).
+        auto half_step = [&](auto basec, int h) {
             constexpr int BASE = decltype(basec)::value;
-            if (sidx < nbatch) {
-                const int64_t F = fs + (int64_t)NB * sidx + CHZ_BATCH * half;
-                cf2 *dst = bufA[sidx & 1] + CHZ_BATCH * half * CHZ_FB;
+            if (h < nh) {
+                const int64_t F = fs + (int64_t)NB * h;
+                cf2 *dst = buf + (h & (CHZ_SLOTS - 1)) * NB * CHZ_FB;
                 chz_ring_wait<P, BASE>(ring);
                 chz_fold_half_ring<P, BASE>(ring, coef, tw1, dst, t);
-                if (in.batch_in_block(F + NB)) chz_load_half_ring<P, BASE, P + 4, true>(ring, in, F + NB, t);
-                else chz_load_half_ring<P, BASE, P + 4, false>(ring, in, F + NB, t);   // generic: zero beyond the data
+                if (in.batch_in_block(F + 2 * NB)) chz_load_half_ring<P, BASE, P + 4, true>(ring, in, F + 2 * NB, t);
+                else chz_load_half_ring<P, BASE, P + 4, false>(ring, in, F + 2 * NB, t);   // generic: zero beyond the data
             }
             __syncthreads();
         };
         constexpr int PERIOD = (P + 4) / 2;                       // half-steps until the ring is back where it started (6)
         static_assert(PERIOD == 6, "the unrolled loop below is written for P = 8");
-        for (int s = 0; s <= nbatch; s += 3) {                    // three time steps = six half-steps = one ring period
-            half_step(std::integral_constant<int, 0>{}, s, 0);
-            half_step(std::integral_constant<int, 2>{}, s, 1);
-            if (s + 1 > nbatch) break;
-            half_step(std::integral_constant<int, 4>{}, s + 1, 0);
-            half_step(std::integral_constant<int, 6>{}, s + 1, 1);
-            if (s + 2 > nbatch) break;
-            half_step(std::integral_constant<int, 8>{}, s + 2, 0);
-            half_step(std::integral_constant<int, 10>{}, s + 2, 1);
+        for (int h = 0; h < nsteps; h += PERIOD) {
+            half_step(std::integral_constant<int, 0>{}, h);
+            if (h + 1 >= nsteps) break;
+            half_step(std::integral_constant<int, 2>{}, h + 1);
+            if (h + 2 >= nsteps) break;
+            half_step(std::integral_constant<int, 4>{}, h + 2);
+            if (h + 3 >= nsteps) break;
+            half_step(std::integral_constant<int, 6>{}, h + 3);
+            if (h + 4 >= nsteps) break;
+            half_step(std::integral_constant<int, 8>{}, h + 4);
+            if (h + 5 >= nsteps) break;
+            half_step(std::integral_constant<int, 10>{}, h + 5);
+        }
+    } else if (wave < 8) {
+        // ------------------------------------------------------------------ pass-2 role
+        const int wf = wave - 4;                                  // frame of the half-batch this wave transforms
+        __syncthreads();                                          // all roles start together
+        for (int i = 0; i < nsteps; i++) {
+            const int h = i - 1;
+            if (h >= 0 && h < nh) chz_p2(buf + ((h & (CHZ_SLOTS - 1)) * NB + wf) * CHZ_FB, lane);
+            __syncthreads();
         }
     } else {
-        // ------------------------------------------------------------------ FFT role
-        const int u = tid - 256;                                  // 0..511: owns bins u and u + 512
-        const int wf = wave - 4;                                  // frame of the batch this wave transforms
-        cf2 tw34[15];                                             // twiddles of the second radix-16 pass: W_1024^{r lane}
+        // ------------------------------------------------------------------ pass-3 + slicer role
+        const int wf = wave - 8;                                  // frame of the half-batch this wave transforms
+        cf2 tw3[15];                                              // twiddles of the second radix-16 pass: W_1024^{r lane}
 #pragma unroll
-        for (int r = 1; r < 16; r++) tw34[r - 1] = chz_twiddle(r * lane, 1024);
-        const cf2 tw2[15] = {};                                   // (pass 2's are applied by the fold waves)
-        ChzSlice2<SL> S;
-        S.reset();
-        uint32_t hold[2][4] = {};                                 // finished ring words of the two bins waiting for their 16-byte store
+        for (int r = 1; r < 16; r++) tw3[r - 1] = chz_twiddle(r * lane, 1024);
+        // Bin ownership: pair j of (wave w, lane l) holds bins 512 j + 128 w + l and + 64: one block of the planar layout, so the
+        // four floats a frame brings for a pair sit at base + {0, 64, 128, 192} (two ds_read2st64_b32), consecutive lanes read
+        // consecutive floats, and the register pairs are (re, re) and (im, im) of the two channels.  A pair-wave whose 128
+        // bins are all outside the active channels is skipped (none at 832 channels from bin 96: every block has active bins).
+        ChzSlicePair<SL> S[2];
+        uint32_t ch[2][2];                                        // channel of the bin (>= n_channels: not an active channel)
+        bool pair_on[2];
+        const int pbase = 256 * wf + lane;                        // chz_planar(128 wf + lane); pair j is 1024 floats further
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            S[j].reset();
+#pragma unroll
+            for (int e = 0; e < 2; e++) ch[j][e] = ((uint32_t)(512 * j + 128 * wf + 64 * e + lane) - a.first_bin) & (M - 1);
+            pair_on[j] = __ballot(ch[j][0] < a.n_channels || ch[j][1] < a.n_channels) != 0;   // wave-uniform
+        }
+        uint32_t hold[2][2][4] = {};                              // finished ring words of the four channels waiting for their 16-byte store
         int nheld = 0;
         const uint64_t mask32 = 2ull * a.ring_words - 1;
-        uint32_t ch[2];
+        __syncthreads();                                          // all roles start together
+        for (int i = 0; i < nsteps; i++) {
+            const int hs = i - 3, h3 = i - 2;
+            if (hs >= 0 && hs < nh) {
+                const int64_t F = fs + (int64_t)NB * hs;          // first frame of the half-batch (multiple of 4)
+                const float *Af = (const float *)(buf + (hs & (CHZ_SLOTS - 1)) * NB * CHZ_FB);
 #pragma unroll
-        for (int j = 0; j < 2; j++) ch[j] = ((uint32_t)(u + 512 * j) - a.first_bin) & (M - 1);
-        __syncthreads();                                          // both roles start together
-        for (int s = 0; s <= nbatch; s++) {
-            cf2 *A = bufA[(s - 1) & 1];
-            if (s >= 1) {
-                cf2 *Af = A + wf * CHZ_FB;
-                chz_p2_t<true>(Af, nullptr, tw2, lane);
-                chz_p34(Af, tw34, lane);
-            }
-            __syncthreads();
-            if (s >= 1) {
-                const int64_t F = fs + (int64_t)NB * (s - 1);     // first frame of the batch (multiple of 8)
-                cf2 y[NB][2];
+                for (int j = 0; j < 2; j++) {
+                    if (!pair_on[j]) continue;
+                    f2 yr[NB], yi[NB];
 #pragma unroll
-                for (int g = 0; g < NB; g++) { y[g][0] = A[g * CHZ_FB + chz_pos2(u)]; y[g][1] = A[g * CHZ_FB + chz_pos2(u + 512)]; }
-                if constexpr (IQ) {
-                    // eight frames of a bin leave as one 64-byte run of the channel-major block
-                    const int ng = (int)(f1 - F < (int64_t)NB ? f1 - F : (int64_t)NB);
+                    for (int g = 0; g < NB; g++) {
+                        const float *q = Af + pbase + g * CHZ_FBF + 1024 * j;
+                        yr[g] = (f2){ q[0], q[64] };
+                        yi[g] = (f2){ q[128], q[192] };
+                    }
+                    if constexpr (IQ) {
+                        // four frames of a bin leave as one 32-byte run of the channel-major block
+                        const int ng = (int)(f1 - F < (int64_t)NB ? f1 - F : (int64_t)NB);
 #pragma unroll
-                    for (int j = 0; j < 2; j++) {
-                        if (ch[j] < a.n_channels) {
-                            float2 *dstp = a.out + (uint64_t)ch[j] * a.ld + F;
-                            if (ng == NB) {
+                        for (int e = 0; e < 2; e++) {
+                            if (ch[j][e] < a.n_channels) {
+                                float2 *dstp = a.out + (uint64_t)ch[j][e] * a.ld + F;
+                                if (ng == NB) {
 #pragma unroll
-                                for (int e = 0; e < NB; e += 2)
-                                    *(float4 *)(dstp + e) = make_float4(y[e][j].x, y[e][j].y, y[e + 1][j].x, y[e + 1][j].y);
-                            } else {
+                                    for (int g = 0; g < NB; g += 2)
+                                        *(float4 *)(dstp + g) = make_float4(yr[g][e], yi[g][e], yr[g + 1][e], yi[g + 1][e]);
+                                } else {
 #pragma unroll
-                                for (int e = 0; e < NB; e++)
-                                    if (e < ng) dstp[e] = make_float2(y[e][j].x, y[e][j].y);
+                                    for (int g = 0; g < NB; g++)
+                                        if (g < ng) dstp[g] = make_float2(yr[g][e], yi[g][e]);
+                                }
                             }
                         }
-                    }
-                } else {
+                    } else {
 #pragma unroll
-                    for (int g = 0; g < NB; g++) { if (g & 1) S.template step<1>(y[g]); else S.template step<0>(y[g]); }
+                        for (int g = 0; g < NB; g++) { if (g & 1) S[j].template step<1>(yr[g], yi[g]); else S[j].template step<0>(yr[g], yi[g]); }
+                    }
+                }
+                if constexpr (!IQ) {
                     if (a.stream_start && F < 0) {                // frames before the stream are exactly +0 (the FFT of zeros may hold -0):
-                        asm volatile("" ::: "memory");            // the state they leave is that of a fresh stream (a real branch, once per launch)
-                        S.reset();
+                        asm volatile("" ::: "memory");            // the state they leave is that of a fresh stream (a real branch, twice per launch)
+                        S[0].reset(); S[1].reset();
                     }
                     if (F >= f0 && ((F + NB - 1) & 31) == 31) {   // 32 real frames collected (f0 is a multiple of 64)
                         // A channel's words leave as ONE 16-byte store per 128 frames (aligned group of four ring dwords): single
@@ -992,27 +621,32 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
                         const uint64_t w = (a.n_done + (uint64_t)(F + NB - 1)) >> 5;   // absolute ring dword of the finished word
                         const bool last = F + NB >= f1;
 #pragma unroll
-                        for (int j = 0; j < 2; j++) {
-                            uint32_t word = S.word(j);
-                            if (SL == AMPS_SLICER_PRODUCT && a.stream_start && F + NB - 1 == 31) word |= 7u;   // no partner yet: g = 1
-                            hold[j][0] = hold[j][1]; hold[j][1] = hold[j][2]; hold[j][2] = hold[j][3]; hold[j][3] = word;
-                        }
+                        for (int j = 0; j < 2; j++)
+#pragma unroll
+                            for (int e = 0; e < 2; e++) {
+                                uint32_t word = S[j].word(e);
+                                if (SL == AMPS_SLICER_PRODUCT && a.stream_start && F + NB - 1 == 31) word |= 7u;   // no partner yet: g = 1
+                                hold[j][e][0] = hold[j][e][1]; hold[j][e][1] = hold[j][e][2]; hold[j][e][2] = hold[j][e][3]; hold[j][e][3] = word;
+                            }
                         nheld++;
                         if ((w & 3) == 3 || last) {
 #pragma unroll
-                            for (int j = 0; j < 2; j++) {
-                                if (ch[j] < a.n_channels) {
-                                    uint32_t *row = (uint32_t *)(a.gring + (uint64_t)ch[j] * a.ring_words);
-                                    if (nheld == 4 && (w & 3) == 3) *(uint4 *)(row + ((w - 3) & mask32)) = make_uint4(hold[j][0], hold[j][1], hold[j][2], hold[j][3]);
-                                    else if (nheld == 2) *(uint2 *)(row + ((w - 1) & mask32)) = make_uint2(hold[j][2], hold[j][3]);
-                                    else for (int k = 0; k < nheld; k++) row[(w - (uint64_t)(nheld - 1 - k)) & mask32] = hold[j][4 - nheld + k];   // not reached: ranges are multiples of 64 frames
+                            for (int j = 0; j < 2; j++)
+#pragma unroll
+                                for (int e = 0; e < 2; e++) {
+                                    if (ch[j][e] < a.n_channels) {
+                                        uint32_t *row = (uint32_t *)(a.gring + (uint64_t)ch[j][e] * a.ring_words);
+                                        if (nheld == 4 && (w & 3) == 3) *(uint4 *)(row + ((w - 3) & mask32)) = make_uint4(hold[j][e][0], hold[j][e][1], hold[j][e][2], hold[j][e][3]);
+                                        else if (nheld == 2) *(uint2 *)(row + ((w - 1) & mask32)) = make_uint2(hold[j][e][2], hold[j][e][3]);
+                                        else for (int k = 0; k < nheld; k++) row[(w - (uint64_t)(nheld - 1 - k)) & mask32] = hold[j][e][4 - nheld + k];   // not reached: ranges are multiples of 64 frames
+                                    }
                                 }
-                            }
                             nheld = 0;
                         }
                     }
                 }
             }
+            if (h3 >= 0 && h3 < nh) chz_p3(buf + ((h3 & (CHZ_SLOTS - 1)) * NB + wf) * CHZ_FB, tw3, lane);
             __syncthreads();
         }
     }
@@ -1041,7 +675,7 @@ struct ChannelizerState {
     int P = 8;
     uint32_t C = 0, first_bin = 0;
     uint32_t max_frames = 0;        // per push
-    uint32_t target_wgs = 512;      // resident workgroups of the filter-bank kernel (2 per CU)
+    uint32_t target_wgs = 256;      // resident workgroups of the filter-bank kernel (one 768-thread workgroup per CU)
     float *taps = nullptr;          // [L]
     float2 *carry[2] = { nullptr, nullptr };
     int carry_cur = 0;
@@ -1053,13 +687,6 @@ struct ChannelizerState {
     size_t stage_samples = 0;
     StageFence stage_fence;
 };
-
-inline bool chz_legacy_kernels()   // AMPS_RECC_CHZ=legacy: the 4-wave kernels also for P = 8 (A/B measurements)
-{
-    static int v = -1;
-    if (v < 0) { const char *e = std::getenv("AMPS_RECC_CHZ"); v = (e && e[0] == 'l') ? 1 : 0; }
-    return v == 1;
-}
 
 inline double bessel_i0(double x)
 {
@@ -1115,9 +742,9 @@ inline void channelizer_destroy(ChannelizerState &z)
 
 inline int channelizer_create(ChannelizerState &z, const amps_recc_cfg_t &cfg, hipStream_t s)
 {
-    if (cfg.wideband_channels != CHZ_M || cfg.wideband_decim != CHZ_D) return -EINVAL;   // round 1: M = 1024, D = 512
+    if (cfg.wideband_channels != CHZ_M || cfg.wideband_decim != CHZ_D) return -EINVAL;   // M = 1024, D = 512
     const int P = cfg.wideband_taps_per_branch ? (int)cfg.wideband_taps_per_branch : 8;
-    if (P != 8 && P != 16) return -EINVAL;
+    if (P != 8) return -EINVAL;                                   // the register ring of chz12_kernel is laid out for eight taps per branch
     if (cfg.n_channels > CHZ_M || cfg.wideband_first_channel >= CHZ_M || cfg.max_samples_per_push == 0) return -EINVAL;
     z.P = P; z.C = cfg.n_channels; z.first_bin = cfg.wideband_first_channel;
     z.max_frames = cfg.max_samples_per_push;
@@ -1134,7 +761,7 @@ inline int channelizer_create(ChannelizerState &z, const amps_recc_cfg_t &cfg, h
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            z.target_wgs = 2u * (uint32_t)prop.multiProcessorCount;
+            z.target_wgs = (uint32_t)prop.multiProcessorCount;
     }
     z.enabled = true;
     (void)s;
@@ -1176,39 +803,19 @@ inline int channelizer_run(ChannelizerState &z, const float2 *iq, size_t nsamp, 
         ChzArgs a{};
         a.block = d; a.carry = z.carry[z.carry_cur]; a.taps = z.taps; a.out = z.out; a.ld = z.ld;
         a.carry_len = z.carry_len; a.nsamp = (uint32_t)nsamp; a.nframes = nframes; a.hist = hist;
-        // one resident round: two workgroups per CU (register-limited); each refills its delay lines (+ 4 pre-roll
-        // frames when fused), so fewer, longer runs are cheaper (measured 1 GiB: 128 frames/WG 0.998 ms, 512 0.976 ms)
-        uint32_t fpw = (nframes + z.target_wgs - 1) / z.target_wgs;
-        fpw = std::max<uint32_t>(fused ? 128u : 64u, fpw);
+        // one resident round of 768-thread workgroups, one per CU; each refills its delay lines and re-runs eight pre-roll
+        // frames when fused, so fewer, longer runs are cheaper
+        uint32_t fpw = std::max<uint32_t>(64u, (nframes + z.target_wgs - 1) / z.target_wgs);
         fpw = (fpw + 63) / 64 * 64;
         a.frames_per_wg = fpw; a.first_bin = z.first_bin; a.n_channels = z.C;
         a.odd_start = 0;
         a.gring = gring; a.ring_words = ring_words; a.n_done = n_done;
         a.stream_start = z.frames_done == 0 ? 1u : 0u;
-        const uint32_t nwg = (nframes + fpw - 1) / fpw;
-        const bool k12 = z.P == 8 && !chz_legacy_kernels();        // the 12-wave pipeline (one workgroup per CU)
-        if (k12) {
-            fpw = std::max<uint32_t>(64u, (nframes + z.target_wgs / 2 - 1) / (z.target_wgs / 2));
-            fpw = (fpw + 63) / 64 * 64;
-            a.frames_per_wg = fpw;
-            const dim3 g12((nframes + fpw - 1) / fpw), b12(768);
-            if (!fused) hipLaunchKernelGGL((chz12_kernel<8, CHZ12_IQ>), g12, b12, 0, s, a);
-            else if (slicer == AMPS_SLICER_PRODUCT) hipLaunchKernelGGL((chz12_kernel<8, AMPS_SLICER_PRODUCT>), g12, b12, 0, s, a);
-            else if (slicer == AMPS_SLICER_SINE) hipLaunchKernelGGL((chz12_kernel<8, AMPS_SLICER_SINE>), g12, b12, 0, s, a);
-            else hipLaunchKernelGGL((chz12_kernel<8, AMPS_SLICER_ATAN_BOXCAR>), g12, b12, 0, s, a);
-        } else if (fused && slicer == AMPS_SLICER_PRODUCT) {
-            if (z.P == 8) hipLaunchKernelGGL((chz_fused_kernel<8, AMPS_SLICER_PRODUCT>), dim3(nwg), dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((chz_fused_kernel<16, AMPS_SLICER_PRODUCT>), dim3(nwg), dim3(256), 0, s, a);
-        } else if (fused && slicer == AMPS_SLICER_SINE) {
-            if (z.P == 8) hipLaunchKernelGGL((chz_fused_kernel<8, AMPS_SLICER_SINE>), dim3(nwg), dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((chz_fused_kernel<16, AMPS_SLICER_SINE>), dim3(nwg), dim3(256), 0, s, a);
-        } else if (fused) {
-            if (z.P == 8) hipLaunchKernelGGL(chz_fused_kernel<8>, dim3(nwg), dim3(256), 0, s, a);
-            else hipLaunchKernelGGL(chz_fused_kernel<16>, dim3(nwg), dim3(256), 0, s, a);
-        } else {
-            if (z.P == 8) hipLaunchKernelGGL(chz_pfb_fft_kernel<8>, dim3(nwg), dim3(256), 0, s, a);
-            else hipLaunchKernelGGL(chz_pfb_fft_kernel<16>, dim3(nwg), dim3(256), 0, s, a);
-        }
+        const dim3 g12((nframes + fpw - 1) / fpw), b12(768);
+        if (!fused) hipLaunchKernelGGL((chz12_kernel<8, CHZ12_IQ>), g12, b12, 0, s, a);
+        else if (slicer == AMPS_SLICER_PRODUCT) hipLaunchKernelGGL((chz12_kernel<8, AMPS_SLICER_PRODUCT>), g12, b12, 0, s, a);
+        else if (slicer == AMPS_SLICER_SINE) hipLaunchKernelGGL((chz12_kernel<8, AMPS_SLICER_SINE>), g12, b12, 0, s, a);
+        else hipLaunchKernelGGL((chz12_kernel<8, AMPS_SLICER_ATAN_BOXCAR>), g12, b12, 0, s, a);
     }
     if (after_main) after_main(after_ctx);                            // timing: the span ends behind the filter-bank kernel, before the carry copy
     const uint32_t consumed = nframes * CHZ_D;                        // virtual samples consumed (incl. leftover)

@@ -109,12 +109,12 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 // v_pk_fma / v_pk_add: measured on MI355X a packed fp32 op issues in ~4.8 cycles per wave against
 // ~4.3 for a scalar one (scripts/ubench_pk.hip), i.e. 1.8x the arithmetic per issue slot, and this
 // kernel is VALU-issue bound.  ~19 instructions per sample instead of ~30.
-// ta, tb = the two conj-products (re, im); everything after them is packed over the two samples
-__device__ __forceinline__ f2 fm_phase_core(f2 ta, f2 tb)
+// re, im = the real and imaginary parts of TWO conj-products (planar: element 0 in .x, element 1 in .y); every operation
+// after them is packed over the two
+__device__ __forceinline__ f2 fm_phase_planar(f2 re, f2 im)
 {
-    const f2 re = { ta.x, tb.x }, im = { ta.y, tb.y };
-    const float axa = __builtin_fabsf(ta.x), aya = __builtin_fabsf(ta.y);
-    const float axb = __builtin_fabsf(tb.x), ayb = __builtin_fabsf(tb.y);
+    const float axa = __builtin_fabsf(re.x), aya = __builtin_fabsf(im.x);
+    const float axb = __builtin_fabsf(re.y), ayb = __builtin_fabsf(im.y);
     const f2 mx = { __builtin_fmaxf(__builtin_fmaxf(axa, aya), AMPS_MX_FLOOR), __builtin_fmaxf(__builtin_fmaxf(axb, ayb), AMPS_MX_FLOOR) };
     const f2 mn = { __builtin_fminf(axa, aya), __builtin_fminf(axb, ayb) };
     f2 r = { __uint_as_float(AMPS_RCP_MAGIC - __float_as_uint(mx.x)), __uint_as_float(AMPS_RCP_MAGIC - __float_as_uint(mx.y)) };
@@ -140,45 +140,10 @@ __device__ __forceinline__ f2 fm_phase_core(f2 ta, f2 tb)
     a.y = re.y < 0.0f ? a_reflect.y : a.y;
     return (f2){ __builtin_copysignf(a.x, im.x), __builtin_copysignf(a.y, im.y) };
 }
-
-// Two independent fm_phase_core evaluations written in lock step (same operations, same order per value, so the
-// results are bit-identical to two separate calls): the Horner / Newton chains are serial, and with the statements of
-// the two pairs alternating the compiler keeps two chains in flight instead of padding one with s_nop.
-__device__ __forceinline__ void fm_phase_core2(f2 ta, f2 tb, f2 tc, f2 td, f2 &out0, f2 &out1)
+// ta, tb = the two conj-products as (re, im) pairs
+__device__ __forceinline__ f2 fm_phase_core(f2 ta, f2 tb)
 {
-    const f2 re0 = { ta.x, tb.x }, im0 = { ta.y, tb.y }, re1 = { tc.x, td.x }, im1 = { tc.y, td.y };
-    const float axa = __builtin_fabsf(ta.x), aya = __builtin_fabsf(ta.y), axb = __builtin_fabsf(tb.x), ayb = __builtin_fabsf(tb.y);
-    const float axc = __builtin_fabsf(tc.x), ayc = __builtin_fabsf(tc.y), axd = __builtin_fabsf(td.x), ayd = __builtin_fabsf(td.y);
-    const f2 mx0 = { __builtin_fmaxf(__builtin_fmaxf(axa, aya), AMPS_MX_FLOOR), __builtin_fmaxf(__builtin_fmaxf(axb, ayb), AMPS_MX_FLOOR) };
-    const f2 mx1 = { __builtin_fmaxf(__builtin_fmaxf(axc, ayc), AMPS_MX_FLOOR), __builtin_fmaxf(__builtin_fmaxf(axd, ayd), AMPS_MX_FLOOR) };
-    const f2 mn0 = { __builtin_fminf(axa, aya), __builtin_fminf(axb, ayb) };
-    const f2 mn1 = { __builtin_fminf(axc, ayc), __builtin_fminf(axd, ayd) };
-    f2 r0 = { __uint_as_float(AMPS_RCP_MAGIC - __float_as_uint(mx0.x)), __uint_as_float(AMPS_RCP_MAGIC - __float_as_uint(mx0.y)) };
-    f2 r1 = { __uint_as_float(AMPS_RCP_MAGIC - __float_as_uint(mx1.x)), __uint_as_float(AMPS_RCP_MAGIC - __float_as_uint(mx1.y)) };
-    const f2 one = { 1.0f, 1.0f };
-    f2 e0, e1;
-#pragma unroll
-    for (int it = 0; it < 3; it++) {
-        e0 = __builtin_elementwise_fma(-mx0, r0, one); e1 = __builtin_elementwise_fma(-mx1, r1, one);
-        r0 = __builtin_elementwise_fma(r0, e0, r0);    r1 = __builtin_elementwise_fma(r1, e1, r1);
-    }
-    const f2 q0 = mn0 * r0, q1 = mn1 * r1;
-    const f2 z0 = q0 * q0, z1 = q1 * q1;
-    f2 p0 = { AMPS_ATAN_C5, AMPS_ATAN_C5 }, p1 = p0;
-    p0 = __builtin_elementwise_fma(p0, z0, (f2){ AMPS_ATAN_C4, AMPS_ATAN_C4 }); p1 = __builtin_elementwise_fma(p1, z1, (f2){ AMPS_ATAN_C4, AMPS_ATAN_C4 });
-    p0 = __builtin_elementwise_fma(p0, z0, (f2){ AMPS_ATAN_C3, AMPS_ATAN_C3 }); p1 = __builtin_elementwise_fma(p1, z1, (f2){ AMPS_ATAN_C3, AMPS_ATAN_C3 });
-    p0 = __builtin_elementwise_fma(p0, z0, (f2){ AMPS_ATAN_C2, AMPS_ATAN_C2 }); p1 = __builtin_elementwise_fma(p1, z1, (f2){ AMPS_ATAN_C2, AMPS_ATAN_C2 });
-    p0 = __builtin_elementwise_fma(p0, z0, (f2){ AMPS_ATAN_C1, AMPS_ATAN_C1 }); p1 = __builtin_elementwise_fma(p1, z1, (f2){ AMPS_ATAN_C1, AMPS_ATAN_C1 });
-    p0 = __builtin_elementwise_fma(p0, z0, (f2){ AMPS_ATAN_C0, AMPS_ATAN_C0 }); p1 = __builtin_elementwise_fma(p1, z1, (f2){ AMPS_ATAN_C0, AMPS_ATAN_C0 });
-    f2 a0 = p0 * q0, a1 = p1 * q1;
-    const f2 s0 = (f2){ AMPS_PI_2_F, AMPS_PI_2_F } - a0, s1 = (f2){ AMPS_PI_2_F, AMPS_PI_2_F } - a1;
-    a0.x = aya > axa ? s0.x : a0.x; a0.y = ayb > axb ? s0.y : a0.y;
-    a1.x = ayc > axc ? s1.x : a1.x; a1.y = ayd > axd ? s1.y : a1.y;
-    const f2 f0 = (f2){ AMPS_PI_F, AMPS_PI_F } - a0, f1 = (f2){ AMPS_PI_F, AMPS_PI_F } - a1;
-    a0.x = re0.x < 0.0f ? f0.x : a0.x; a0.y = re0.y < 0.0f ? f0.y : a0.y;
-    a1.x = re1.x < 0.0f ? f1.x : a1.x; a1.y = re1.y < 0.0f ? f1.y : a1.y;
-    out0 = (f2){ __builtin_copysignf(a0.x, im0.x), __builtin_copysignf(a0.y, im0.y) };
-    out1 = (f2){ __builtin_copysignf(a1.x, im1.x), __builtin_copysignf(a1.y, im1.y) };
+    return fm_phase_planar((f2){ ta.x, tb.x }, (f2){ ta.y, tb.y });
 }
 
 // t = x * conj(p): (re, im) = (xr*pr + xi*pi, xi*pr - xr*pi), packed over (re, im)
@@ -204,12 +169,6 @@ __device__ __forceinline__ f2 fm_phase_pair(float4 s, float pr, float pi_)
 __device__ __forceinline__ f2 fm_phase_two(f2 x0, f2 p0, f2 x1, f2 p1)
 {
     return fm_phase_core(conj_product(x0, p0), conj_product(x1, p1));
-}
-
-// four independent streams at once (the four bins a lane owns behind the channelizer's FFT)
-__device__ __forceinline__ void fm_phase_four(const f2 (&x)[4], const f2 (&p)[4], f2 &d01, f2 &d23)
-{
-    fm_phase_core2(conj_product(x[0], p[0]), conj_product(x[1], p[1]), conj_product(x[2], p[2]), conj_product(x[3], p[3]), d01, d23);
 }
 
 // Per-wave LDS demod buffers (two, used alternately): 16 floats of history (the tail of the previous

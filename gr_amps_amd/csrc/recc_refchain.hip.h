@@ -154,7 +154,12 @@ __global__ __launch_bounds__(64) void ref_mm_kernel(float *d, uint64_t dld, uint
     }
     // what the loop did not consume waits in front of the next push (ii may have stepped past the data by < 11)
     // (source index - destination index = nsamp >= 0: an ascending copy never overwrites what it still has to read)
-    const uint32_t keep = ii < n ? n - ii : 0;        // < 8 + 11 <= REF_TAIL: the loop stops within 8 samples of the end and steps < 11
+    // < 8 + 11 <= REF_TAIL when the loop stopped at the end of the data (it stops within 8 samples of it and steps < 11).  If it
+    // stopped because the symbol row is full instead (cannot happen while omega is held within 0.5 % of 10 and sym_cap =
+    // max/9 + 16, but nothing else enforces it), only the newest REF_TAIL samples can be carried: the older ones are dropped
+    // rather than written in front of the row.
+    uint32_t keep = ii < n ? n - ii : 0;
+    if (keep > (uint32_t)REF_TAIL) { ii += keep - (uint32_t)REF_TAIL; keep = (uint32_t)REF_TAIL; }
     float *base = d + (uint64_t)c * dld;
     for (uint32_t k = 0; k < keep; k++) base[REF_TAIL - keep + k] = row[ii + k];
     m.tail = keep;

@@ -1,5 +1,6 @@
 // recc_bank_impl.cc -- gr::amps::recc_bank: C byte-symbol streams in, (channel, burst blob) pairs out; one device launch per work().
 #include <amps/recc_bank.h>
+#include <cerrno>
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
@@ -44,7 +45,8 @@ public:
             for (int c = 0; c < d_C; c++) std::memcpy(&d_stage[(size_t)c * n], (const unsigned char *)input_items[c] + done, (size_t)n);
             size_t nout = 0;
             int rc = amps_recc_push_symbols(d_handle, d_stage.data(), (size_t)n, n, AMPS_MEM_HOST, d_bursts.data(), d_chan.data(), (size_t)d_C, &nout);
-            if (rc != 0) { std::fprintf(stderr, "amps::recc_bank: %s\n", amps_recc_strerror(rc)); return WORK_DONE; }
+            if (rc == -ENOSPC) std::fprintf(stderr, "amps::recc_bank: %s (bursts dropped, continuing)\n", amps_recc_strerror(rc));   // recoverable
+            else if (rc != 0) { std::fprintf(stderr, "amps::recc_bank: %s\n", amps_recc_strerror(rc)); return WORK_DONE; }
             for (size_t i = 0; i < nout; i++)
                 message_port_pub(pmt::mp("bursts"), pmt::cons(pmt::from_long((long)d_chan[i]),
                                                               pmt::mp(d_bursts.data() + i * AMPS_RECC_CAPTURE_SYMS, AMPS_RECC_CAPTURE_SYMS)));

@@ -3,6 +3,9 @@
 // decode, the 35 BCH decodes, the field parse and the dispatch run on the MI355X
 // (amps_recc_decode_bursts); the reply words come from amps_recc_reply_words.
 #include "recc_decode_impl.h"
+#ifdef AMPS_WITH_GNURADIO
+#include <boost/bind.hpp>
+#endif
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
@@ -23,9 +26,15 @@ recc_decode_impl::recc_decode_impl()
     int rc = amps_recc_create(&d_handle, &cfg);
     if (rc != 0) throw std::runtime_error(std::string("amps::recc_decode: ") + amps_recc_strerror(rc));
     message_port_register_in(pmt::mp("bursts"));                                        // :38
-    set_msg_handler(pmt::mp("bursts"), [this](pmt::pmt_t m) { bursts_message(m); });    // :39-41
     message_port_register_in(pmt::mp("records"));                                       // extra: from recc_fused
+#ifdef AMPS_WITH_GNURADIO
+    // GNU Radio 3.7's msg_handler_t is a boost::function: the reference's own registration form (:39-41)
+    set_msg_handler(pmt::mp("bursts"), boost::bind(&recc_decode_impl::bursts_message, this, _1));
+    set_msg_handler(pmt::mp("records"), boost::bind(&recc_decode_impl::records_message, this, _1));
+#else
+    set_msg_handler(pmt::mp("bursts"), [this](pmt::pmt_t m) { bursts_message(m); });    // :39-41
     set_msg_handler(pmt::mp("records"), [this](pmt::pmt_t m) { records_message(m); });
+#endif
     message_port_register_out(pmt::mp("focc_words"));                                   // :42-46
     message_port_register_out(pmt::mp("fvc_words"));
     message_port_register_out(pmt::mp("audio_mute"));

@@ -3,6 +3,7 @@
 // Replaces quadrature_demod_cf -> clock_recovery_mm_ff -> binary_slicer_fb -> amps_recc with the fused
 // MI355X kernel (amps_recc_push_iq / amps_recc_drain).
 #include <amps/recc_fused.h>
+#include <cerrno>
 #include <cstdio>
 #include <stdexcept>
 #include <vector>
@@ -63,7 +64,10 @@ public:
             amps_recc_burst_t recs[kMaxRecs];
             size_t nrec = 0;
             rc = amps_recc_drain_bursts(d_handle, recs, d_bursts.data(), kMaxRecs, &nrec);
-            if (rc != 0) { std::fprintf(stderr, "amps::recc_fused: %s\n", amps_recc_strerror(rc)); return WORK_DONE; }
+            // -ENOSPC: more bursts than the list holds were found; the ones that fit are returned and the list recovers on the
+            // next push -- a recoverable condition must not end the flow graph
+            if (rc == -ENOSPC) std::fprintf(stderr, "amps::recc_fused: %s (bursts dropped, continuing)\n", amps_recc_strerror(rc));
+            else if (rc != 0) { std::fprintf(stderr, "amps::recc_fused: %s\n", amps_recc_strerror(rc)); return WORK_DONE; }
             for (size_t i = 0; i < nrec; i++) {
                 message_port_pub(pmt::mp("bursts"), pmt::mp(d_bursts.data() + i * AMPS_RECC_CAPTURE_SYMS, AMPS_RECC_CAPTURE_SYMS));
                 message_port_pub(pmt::mp("records"), pmt::mp(&recs[i], sizeof(recs[i])));

@@ -1,5 +1,6 @@
 // recc_wideband_impl.cc -- gr::amps::recc_wideband: one 30.72 Msps complex stream in, (channel, burst) and (channel, record) pairs out.
 #include <amps/recc_wideband.h>
+#include <cerrno>
 #include <cstdio>
 #include <stdexcept>
 #include <vector>
@@ -50,7 +51,10 @@ public:
             if (rc != 0) { std::fprintf(stderr, "amps::recc_wideband: %s\n", amps_recc_strerror(rc)); return WORK_DONE; }
             size_t nrec = 0;
             rc = amps_recc_drain_bursts(d_handle, d_recs.data(), d_bursts.data(), kMaxRecs, &nrec);
-            if (rc != 0) { std::fprintf(stderr, "amps::recc_wideband: %s\n", amps_recc_strerror(rc)); return WORK_DONE; }
+            // -ENOSPC: more bursts than the list holds were found; the ones that fit are returned and the list recovers on the
+            // next push -- a recoverable condition must not end the flow graph
+            if (rc == -ENOSPC) std::fprintf(stderr, "amps::recc_wideband: %s (bursts dropped, continuing)\n", amps_recc_strerror(rc));
+            else if (rc != 0) { std::fprintf(stderr, "amps::recc_wideband: %s\n", amps_recc_strerror(rc)); return WORK_DONE; }
             for (size_t i = 0; i < nrec; i++) {
                 const pmt::pmt_t ch = pmt::from_long((long)d_recs[i].channel);
                 message_port_pub(pmt::mp("bursts"), pmt::cons(ch, pmt::mp(d_bursts.data() + i * AMPS_RECC_CAPTURE_SYMS, AMPS_RECC_CAPTURE_SYMS)));

@@ -61,7 +61,9 @@ extern "C" {
 #define AMPS_RECC_FLAG_SLICER_PRODUCT 0x8u /* IQ / wideband seams: slicer spec B of amps_recc_numerics.h (sign of
                                                Im(x[n] conj(x[n-sps])), the telescoped form of discriminator + boxcar) */
 #define AMPS_RECC_FLAG_SLICER_SINE  0x10u /* IQ / wideband seams: slicer spec C (boxcar over Im(x[n] conj(x[n-1])): spec A without the
-                                               arctangent).  At most one of the two SLICER flags may be set */
+                                               arctangent).  At most one of the three SLICER flags may be set */
+#define AMPS_RECC_FLAG_SLICER_ATAN  0x40u /* IQ / wideband seams: slicer spec A (arctangent discriminator + boxcar), explicitly.
+                                               With no SLICER flag a handle uses amps_recc_default_slicer() */
 #define AMPS_RECC_FLAG_KEEP_BURSTS  0x20u /* IQ / wideband seams: also keep the 3374 captured symbol bytes of every burst (what
                                                gr::amps::recc publishes on "bursts", lib/recc_impl.cc:126) for amps_recc_drain_bursts */
 #define AMPS_RECC_FLAG_MAJORITY     0x2u /* decode mode "majority" instead of "reference" (SURVEY.md 8f.2), see below */
@@ -167,6 +169,8 @@ typedef struct amps_recc amps_recc_t; /* opaque; owns device buffers + per-chann
 
 /* version / introspection */
 int         amps_recc_abi_version(void);
+/* the numeric slicer spec (AMPS_SLICER_* of amps_recc_numerics.h) of a handle created with no SLICER flag */
+int         amps_recc_default_slicer(void);
 const char *amps_recc_strerror(int code);
 size_t      amps_recc_burst_size(void);   /* sizeof(amps_recc_burst_t), for binding self-checks */
 

@@ -93,5 +93,6 @@
 #define AMPS_SLICER_ATAN_BOXCAR 0  /* spec A: discriminator + boxcar (default)                      */
 #define AMPS_SLICER_PRODUCT     1  /* spec B: sign of Im(x[n] conj(x[n-sps]))                        */
 #define AMPS_SLICER_SINE        2  /* spec C: boxcar over Im(x[n] conj(x[n-1])), no arctangent       */
+#define AMPS_SLICER_DEFAULT     AMPS_SLICER_ATAN_BOXCAR  /* what a handle created with no SLICER flag uses (amps_recc_default_slicer) */
 
 #endif

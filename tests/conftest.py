@@ -4,6 +4,8 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# every drain of the suite cross-checks the list header the capture kernel published against the device-side counters
+os.environ.setdefault("AMPS_RECC_CHECK_HEADER", "1")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

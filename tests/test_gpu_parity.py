@@ -477,11 +477,9 @@ def test_hold_off_chains_match_the_sequential_rule(gpu):
 
 
 @pytest.mark.parametrize("sps,slicer", [(3, "sine"), (10, "sine"), (12, "sine"), (5, "atan"), (10, "atan")])
-def test_cooperative_front_kernel_matches_the_cpu_model(gpu, monkeypatch, sps, slicer):
-    """AMPS_RECC_COOP=4 selects recc_front_coop_kernel (four waves of a workgroup on four consecutive tiles, shared LDS bit
-    ring, deferred run-start pass): same records as the CPU model, byte for byte, on ragged pushes that cut bursts, with
-    several channels per workgroup span and with spans that cross channel boundaries."""
-    monkeypatch.setenv("AMPS_RECC_COOP", "4")
+def test_spans_across_channel_boundaries_and_ragged_pushes(gpu, sps, slicer):
+    """Five channels, so that the wave spans of the streaming kernel cross channel boundaries and several channels share a
+    span: same records as the CPU model, byte for byte, in one push and on ragged pushes that cut bursts."""
     C = 5
     N = 3 * 3600 * 2 * sps + 7000
     rng = np.random.default_rng(900 + sps)
