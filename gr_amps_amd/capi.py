@@ -118,7 +118,8 @@ def load():
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.amps_recc_abi_version.restype = C.c_int
-    L.amps_recc_default_slicer.restype = C.c_int
+    if hasattr(L, "amps_recc_default_slicer"):      # absent only from A/B builds of earlier revisions (AMPS_RECC_LIB)
+        L.amps_recc_default_slicer.restype = C.c_int
     L.amps_recc_strerror.argtypes = [C.c_int]
     L.amps_recc_strerror.restype = C.c_char_p
     L.amps_recc_burst_size.restype = C.c_size_t
@@ -150,6 +151,8 @@ def load():
     L.amps_bch_encode_words.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, vp]
     L.amps_bch_decode_words.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, vp, vp, vp]
     for name in EXPORTS:
+        if name == "amps_recc_default_slicer" and not hasattr(L, name):
+            continue
         if name not in ("amps_recc_strerror", "amps_recc_burst_size", "amps_recc_destroy"):   # every other entry point returns int
             getattr(L, name).restype = C.c_int
     if L.amps_recc_burst_size() != BURST_DTYPE.itemsize:
@@ -189,7 +192,7 @@ class Recc:
         L = load()
         if isinstance(slicer, bool) or slicer not in _SLICER_FLAGS:        # a typo must not run a different numeric spec silently
             raise ValueError("slicer must be one of %r" % sorted(map(str, _SLICER_FLAGS)))
-        self.slicer = SLICER_NAMES[L.amps_recc_default_slicer()] if _SLICER_FLAGS[slicer] == 0 else \
+        self.slicer = SLICER_NAMES[L.amps_recc_default_slicer() if hasattr(L, "amps_recc_default_slicer") else 0] if _SLICER_FLAGS[slicer] == 0 else \
             {FLAG_SLICER_ATAN: "atan", FLAG_SLICER_PRODUCT: "product", FLAG_SLICER_SINE: "sine"}[_SLICER_FLAGS[slicer]]
         self.sync_torch = sync_torch
         cfg = Cfg()

@@ -78,6 +78,7 @@ struct ChzArgs {
     uint32_t ring_words;
     uint64_t n_done;         // absolute channel-stream sample index of frame 0 (multiple of 64)
     uint32_t stream_start;   // frame 0 of this launch is the first frame of the stream (spec B: its first 3 bits are ones)
+    unsigned long long *tl;  // CHZ_TIMELINE builds: s_memtime stamps of workgroup 0 ([wave][step][8]), else unused
 };
 constexpr int CHZ_PRE = 4;   // frames of history the carry keeps beyond the filter's own L - D samples: what the exact half of a workgroup's pre-roll reaches back to
 
@@ -136,6 +137,9 @@ __device__ __forceinline__ cf2 fma_hi(cf2 a, cf2 c, cf2 s)
 
 // ---- frame geometry ----
 // A half-batch = four frames (what the fold role produces per time step); a frame buffer holds one 1024-point frame.
+#ifndef CHZ_TW2
+#define CHZ_TW2 0                                              // who applies pass 2's input twiddles: 0 the fold role, 1 the pass-2 role (experiment)
+#endif
 constexpr int CHZ_BATCH = 4;
 constexpr int CHZ_FB = CHZ_M + CHZ_M / 16;                     // padded frame buffer, cf2 elements
 constexpr int CHZ_FBF = 2 * CHZ_FB;                            // ... in floats
@@ -174,14 +178,23 @@ static_assert(chz_pos1(255, 3) < CHZ_FB && chz_pos2(1023) < CHZ_FB && chz_planar
 // X = DFT16(u), A[16 (i - k) + k + 4 r] = X[r].  The input twiddles W_64^{r k} have already been applied by the fold role
 // (chz_fold2_ring): read from an LDS table here, one pair at a time between the multiplies, they cost eight exposed LDS
 // latencies per pass (measured with s_memtime: 2950 cycles per frame against 1780 for pass 3).
-__device__ __forceinline__ void chz_p2(cf2 *A, int lane)
+__device__ __forceinline__ void chz_p2(cf2 *A, int lane, const cf2 (&tw2)[15])
 {
+#ifdef CHZ_SKIP_FFT
+    return;
+#endif
     const int k = lane & 3;
     cf2 u[16];
     // pass 1 left element 4 t + k1 at chz_pos1(t, k1): lane i wants 4 t + k1 = i + 64 r, i.e. t = (i >> 2) + 16 r, k1 = i & 3
     const cf2 *src = A + chz_pos1(lane >> 2, k);
 #pragma unroll
     for (int r = 0; r < 16; r++) u[r] = src[16 * r];
+#if CHZ_TW2 == 1
+#pragma unroll
+    for (int r = 1; r < 16; r++) u[r] = cmul(u[r], tw2[r - 1]);
+#else
+    (void)tw2;
+#endif
     // DFT16 = 4 x DFT4 over a (s = 4a + b), twiddle W16^{bc}, 4 x DFT4 over b -> X[c + 4d]
     cf2 v[4][4];
 #pragma unroll
@@ -210,8 +223,14 @@ __device__ __forceinline__ void chz_p2(cf2 *A, int lane)
 // pass 3 of the 4 x 16 x 16 factorisation, radix 16, p = 64, one frame per wave:
 //   lane i: u[r] = A[i + 64 r] W_1024^{r i};  bin i + 64 q = DFT16(u)[q]   (natural order, planar layout over the same buffer:
 //   every output depends on all sixteen inputs, so the reads have returned before the first store is issued)
-__device__ __forceinline__ void chz_p3(cf2 *A, const cf2 (&tw)[15], int lane)
+template <int NT>
+__device__ __forceinline__ void chz_p3(cf2 *A, const cf2 (&tw)[NT], int lane)
 {
+    static_assert(NT == 15 || NT == 1, "fifteen twiddles (NT = 1: the role that does not run pass 3)");
+#ifdef CHZ_SKIP_FFT
+    return;
+#endif
+    if constexpr (NT == 15) {
     cf2 u[16];
     const cf2 *src = A + lane;                                  // chz_pos2(lane + 64 r) = lane + 68 r
 #pragma unroll
@@ -238,6 +257,7 @@ __device__ __forceinline__ void chz_p3(cf2 *A, const cf2 (&tw)[15], int lane)
         dft4(v[0][c], v[1][c], v[2][c], v[3][c], X);
 #pragma unroll
         for (int d = 0; d < 4; d++) { dst[chz_planar(64 * (c + 4 * d))] = X[d].x; dst[chz_planar(64 * (c + 4 * d)) + 128] = X[d].y; }
+    }
     }
 }
 
@@ -320,8 +340,10 @@ __device__ __forceinline__ void chz_fold_taps2(cf2 (&acc)[2][4], const cf2 (&x0)
 }
 // frames FA, FA+1 of a half-step (FA = 0: tap windows start at SA = 1 / SB = 0 and 1 / 1; FA = 2: 2 / 1 and 2 / 2), then the
 // radix-4 pass 1 of both -> A[FA], A[FA+1]
-template <int P, int BASE, int FA>
-__device__ __forceinline__ void chz_fold2_ring(const cf2 (&ring)[4][P + 4], const cf2 (&coef)[4][P / 2], const cf2 (&tw1)[3], cf2 *bufA, int t)
+// `after_first` runs behind the first tap block (q = 0): that block holds the last uses of the two oldest elements of the
+// ring's current view, so the caller refills those slots from there (chz_load1_ring)
+template <int P, int BASE, int FA, typename Hook>
+__device__ __forceinline__ void chz_fold2_ring(const cf2 (&ring)[4][P + 4], const cf2 (&coef)[4][P / 2], const cf2 (&tw1)[3], cf2 *bufA, int t, Hook &&after_first)
 {
     constexpr int R = P + 4;
     constexpr int S[2][2] = { { FA == 0 ? 1 : 2, FA == 0 ? 0 : 1 }, { FA == 0 ? 1 : 2, FA == 0 ? 1 : 2 } };   // [frame][jb >= 2]
@@ -338,7 +360,7 @@ __device__ __forceinline__ void chz_fold2_ring(const cf2 (&ring)[4][P + 4], cons
             }
 #pragma unroll
         for (int j = 0; j < 4; j++) c[j] = coef[j][q / 2];
-        if (q == 0) chz_fold_taps2<true>(acc, x0, x1, c); else chz_fold_taps2<false>(acc, x0, x1, c);
+        if (q == 0) { chz_fold_taps2<true>(acc, x0, x1, c); after_first(); } else chz_fold_taps2<false>(acc, x0, x1, c);
     }
 #pragma unroll
     for (int f = 0; f < 2; f++) {
@@ -347,43 +369,60 @@ __device__ __forceinline__ void chz_fold2_ring(const cf2 (&ring)[4][P + 4], cons
         // the input twiddles of pass 2 (element 4 t + k1 is its point r = t >> 4 of lane 4 (t & 15) + k1: W_64^{r k1}) are applied
         // HERE: the fold waves wait at the barriers more than half of the time, the FFT waves are the critical path of a time step
         cf2 *d = bufA + (FA + f) * CHZ_FB + t;
+#if CHZ_TW2 == 0
         d[chz_pos1(0, 0)] = o[0]; d[chz_pos1(0, 1)] = cmul(o[1], tw1[0]); d[chz_pos1(0, 2)] = cmul(o[2], tw1[1]); d[chz_pos1(0, 3)] = cmul(o[3], tw1[2]);
+#else
+        (void)tw1;
+        d[chz_pos1(0, 0)] = o[0]; d[chz_pos1(0, 1)] = o[1]; d[chz_pos1(0, 2)] = o[2]; d[chz_pos1(0, 3)] = o[3];
+#endif
     }
 }
-template <int P, int BASE>
-__device__ __forceinline__ void chz_fold_half_ring(const cf2 (&ring)[4][P + 4], const cf2 (&coef)[4][P / 2], const cf2 (&tw1)[3], cf2 *bufA, int t)
+// The two samples frame F + G brings for this thread go to branches 2 (G & 1) + {0, 1}, logical element ELEM + (G >> 1).
+// FAST (the four frames of the half-batch lie inside the new block): the loads are issued as inline asm, so that the compiler
+// does not track them -- its own bookkeeping puts `s_waitcnt vmcnt(0)` behind every barrier of the loop (the fast / generic
+// join makes it conservative), which drains the loads issued a moment ago.  The fold waits with chz_ring_wait instead: vmcnt(8)
+// = "everything but the eight youngest loads", i.e. exactly the loads of the previous half-step stay in flight.  The address is
+// a wave-uniform SGPR base plus the lane's constant byte offset (saddr form: no per-load address arithmetic on the VALU, one
+// address dword to move instead of two: with 64-bit VGPR addresses the eight loads of a half-step took the fold waves ~350
+// cycles at the END of their step, when every other wave of the CU was already waiting at the barrier).
+// The generic path (carry, zero padding: first and last half-steps of a launch) uses ordinary loads and drains them before it
+// returns, so vmcnt(8) is right after either path.
+template <int P, int BASE, int ELEM, int G, bool FAST>
+__device__ __forceinline__ void chz_load1_ring(cf2 (&ring)[4][P + 4], const ChzIn &in, int64_t F, int t)
 {
-    chz_fold2_ring<P, BASE, 0>(ring, coef, tw1, bufA, t);
-    chz_fold2_ring<P, BASE, 2>(ring, coef, tw1, bufA, t);
+    constexpr int R = P + 4;
+    constexpr int E = (BASE + ELEM + (G >> 1)) % R, J = 2 * (G & 1);
+    if constexpr (FAST) {
+        const uint32_t voff = (uint32_t)t * (uint32_t)sizeof(float2);
+        // wave-uniform; clamped to the last whole frame of the block: the prefetch runs two half-steps ahead of the fold and so
+        // up to eight frames past the end of the data -- those loads fetch valid memory nobody folds
+        int64_t off = (F + G) * CHZ_D - in.lead;
+        if (off > in.nsamp - CHZ_D) off = in.nsamp - CHZ_D;
+        const float2 *q = in.block + off;
+        // "+v": the destination is TIED to the register that holds the slot's dead value, so the new value is born in the ring's own
+        // register -- with "=v" the compiler is free to load into a scratch pair and copy it into place at the next control-flow
+        // join, i.e. to READ a register whose load is still in flight (it did: tests/test_cpu_inflight_loads.py scans the
+        // assembly for any access to such a register before the wait that covers it)
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(ring[J][E]) : "v"(voff), "s"(q));
+        asm volatile("global_load_dwordx2 %0, %1, %2 offset:2048" : "+v"(ring[J + 1][E]) : "v"(voff), "s"(q));
+    } else {
+        cf2 s0, s1;
+        in.template frame<false>(F + G, t, s0, s1);
+        // a use of both values: the compiler drains its loads HERE and carries no pending load out of this path; they then move
+        // into the slot's own registers through the same tie as the fast path's loads, so that the two paths join with the ring
+        // where it is and the compiler has nothing to copy behind an in-flight load
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(s0), "+v"(s1) :: "memory");
+        asm volatile("v_mov_b64 %0, %1" : "+v"(ring[J][E]) : "v"(s0));
+        asm volatile("v_mov_b64 %0, %1" : "+v"(ring[J + 1][E]) : "v"(s1));
+    }
 }
-// the two samples frame F + g brings for this thread go to branches 2 (g & 1) + {0, 1}, logical element ELEM + (g >> 1).
-// FAST (the four frames lie inside the new block): the eight loads are issued as inline asm, so that the compiler does not
-// track them -- its own bookkeeping puts `s_waitcnt vmcnt(0)` behind every barrier of the loop (the fast / generic join
-// makes it conservative), which drains the loads issued a moment ago and halves the lead a load has.  The fold waits with
-// chz_ring_wait instead: vmcnt(8) = "everything but the eight youngest loads", i.e. exactly the loads of the previous
-// half-step stay in flight.  The generic path (carry, zero padding: first and last half-steps of a launch) uses ordinary
-// loads and drains them before it returns, so vmcnt(8) is right after either path.
 template <int P, int BASE, int ELEM, bool FAST>
 __device__ __forceinline__ void chz_load_half_ring(cf2 (&ring)[4][P + 4], const ChzIn &in, int64_t F, int t)
 {
-    constexpr int R = P + 4;
-    if constexpr (FAST) {
-        const float2 *p = in.block + (F * CHZ_D - in.lead) + t;
-#pragma unroll
-        for (int g = 0; g < CHZ_BATCH; g++) {
-            const float2 *q = p + g * CHZ_D;
-            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(ring[2 * (g & 1)][(BASE + ELEM + (g >> 1)) % R]) : "v"(q));
-            asm volatile("global_load_dwordx2 %0, %1, off offset:2048" : "=v"(ring[2 * (g & 1) + 1][(BASE + ELEM + (g >> 1)) % R]) : "v"(q));
-        }
-    } else {
-#pragma unroll
-        for (int g = 0; g < CHZ_BATCH; g++)
-            in.template frame<false>(F + g, t, ring[2 * (g & 1)][(BASE + ELEM + (g >> 1)) % R], ring[2 * (g & 1) + 1][(BASE + ELEM + (g >> 1)) % R]);
-        // a use of all eight destinations: the compiler drains its loads HERE and carries no pending load out of this path
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[0][(BASE + ELEM) % R]), "+v"(ring[1][(BASE + ELEM) % R]), "+v"(ring[2][(BASE + ELEM) % R]),
-                     "+v"(ring[3][(BASE + ELEM) % R]), "+v"(ring[0][(BASE + ELEM + 1) % R]), "+v"(ring[1][(BASE + ELEM + 1) % R]),
-                     "+v"(ring[2][(BASE + ELEM + 1) % R]), "+v"(ring[3][(BASE + ELEM + 1) % R]) :: "memory");
-    }
+    chz_load1_ring<P, BASE, ELEM, 0, FAST>(ring, in, F, t);
+    chz_load1_ring<P, BASE, ELEM, 1, FAST>(ring, in, F, t);
+    chz_load1_ring<P, BASE, ELEM, 2, FAST>(ring, in, F, t);
+    chz_load1_ring<P, BASE, ELEM, 3, FAST>(ring, in, F, t);
 }
 // before a fold: the samples of logical elements P and P+1 (loaded two half-steps ago) have arrived; the empty asm makes
 // every use of those registers depend on the wait
@@ -403,7 +442,7 @@ __device__ __forceinline__ void chz_ring_wait(cf2 (&ring)[4][P + 4])
 // waves in the same phase shared every SIMD, and the slicer sat on their critical path behind a second barrier (VALU issue
 // slots 0.57 busy, waves parked 39 % of their cycles).  Here a time step is FOUR frames and every SIMD holds three waves in
 // three different phases:
-//   waves 0..3  "fold"  : thread t keeps branches t + 256 j as a register ring, folds the four frames of half-batch h and runs
+//   "fold"  : thread t keeps branches t + 256 j as a register ring, folds the four frames of half-batch h and runs
 //                         the radix-4 pass 1 (+ pass 2's input twiddles) on its own registers -> slot h & 3.  Pure VALU +
 //                         prefetched global loads.
 //   waves 4..7  "pass 2": wave w transforms frame w of half-batch h - 1 (radix 16, p = 4), in place.
@@ -462,6 +501,21 @@ template <int SL> struct ChzSlicePair {
     __device__ __forceinline__ uint32_t word(int e) const { return SL == AMPS_SLICER_ATAN_BOXCAR ? gw[e] : ~__builtin_bitreverse32(gw[e]); }
 };
 
+// Timeline hook (builds with -DCHZ_TIMELINE only; scripts/chz_timeline.py): every wave of workgroup 0 accumulates, in registers,
+// the s_memtime spent between its phase boundaries over the time steps >= CHZ_TL_FIRST and writes the sums once, at the end
+// (no memory traffic inside the loop: stores would count in the fold role's vmcnt window and stall it)
+constexpr int CHZ_TL_FIRST = 40;
+#ifdef CHZ_TIMELINE
+#define CHZ_TL_DECL long long tl_acc[6] = {}, tl_last = 0
+#define CHZ_STAMP(step, k) do { if ((step) >= CHZ_TL_FIRST) { const long long now_ = (long long)__builtin_amdgcn_s_memtime(); \
+        if (tl_last) tl_acc[k] += now_ - tl_last; tl_last = now_; if ((k) == 4) tl_acc[5]++; } } while (0)
+#define CHZ_TL_FLUSH do { if (a.tl && blockIdx.x == 0 && lane == 0) for (int k_ = 0; k_ < 6; k_++) a.tl[wave * 8 + k_] = (unsigned long long)tl_acc[k_]; } while (0)
+#else
+#define CHZ_TL_DECL
+#define CHZ_STAMP(step, k) do { } while (0)
+#define CHZ_TL_FLUSH do { } while (0)
+#endif
+
 template <int P, int MODE>
 __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
 {
@@ -472,6 +526,28 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
+    // Role of a wave.  The hardware arbitrates VALU issue between the waves of a SIMD by priority, then by age: the fold role is
+    // pure VALU and would starve the two roles that alternate LDS round trips with short VALU bursts -- their latency chains
+    // would then run AFTER the fold instead of beside it (measured: 0.45 ms per GiB with the fold in the oldest waves and no
+    // priorities, against 0.38 for round 2's kernel).  So the latency-bound roles get the oldest waves and a higher priority.
+#ifndef CHZ_ORDER
+#define CHZ_ORDER 1
+#endif
+#ifndef CHZ_PRIO
+#define CHZ_PRIO 1
+#endif
+    const int role = CHZ_ORDER == 0 ? wave >> 2 : 2 - (wave >> 2);      // 0 fold, 1 pass 2, 2 pass 3 + slicer
+    // Which role runs pass 3.  Behind the cheap slicers (specs B, C: ~7 instructions per channel pair and frame) it shares the
+    // slicer's waves; spec A's arctangent makes the slicer the longest chain of a time step (~90 instructions per pair and
+    // frame, serial Newton / Horner chains), so there pass 3 moves to the pass-2 waves.
+#ifndef CHZ_SPLIT
+#define CHZ_SPLIT 1
+#endif
+    constexpr bool P3_WITH_P2 = CHZ_SPLIT == 2 || (CHZ_SPLIT == 1 && !IQ && SL == AMPS_SLICER_ATAN_BOXCAR);
+    const int wf = wave & 3;                                            // frame of a half-batch this wave transforms (roles 1, 2)
+    if (CHZ_PRIO == 1) { if (role == 2) __builtin_amdgcn_s_setprio(2); else if (role == 1) __builtin_amdgcn_s_setprio(1); }
+    if (CHZ_PRIO == 2) { if (role != 0) __builtin_amdgcn_s_setprio(1); }
+    if (CHZ_PRIO == 3) { if (role == 1) __builtin_amdgcn_s_setprio(2); else if (role == 2) __builtin_amdgcn_s_setprio(1); }
     const int64_t f0 = (int64_t)blockIdx.x * a.frames_per_wg;   // multiple of 64
     if (f0 >= (int64_t)a.nframes) return;
     int64_t f1 = f0 + a.frames_per_wg; if (f1 > (int64_t)a.nframes) f1 = a.nframes;
@@ -479,11 +555,12 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
     // only primes the delay lines for the second, which is exact (the carry holds L - D + 4 D samples)
     const int64_t fs = IQ ? f0 : f0 - CHZ_PREROLL;
     const int nh = (int)((f1 - fs + NB - 1) / NB);              // half-batches of this workgroup
+    CHZ_TL_DECL;
     const int nsteps = nh + 3;                                    // time step i: fold h = i, pass 2 h = i - 1, pass 3 h = i - 2, slicer h = i - 3
 
-    if (wave < 4) {
+    if (role == 0) {
         // ------------------------------------------------------------------ fold role
-        const int t = tid;
+        const int t = tid & 255;
         const ChzIn in{ a.block, a.carry, (int64_t)a.hist, (int64_t)a.carry_len - (int64_t)a.hist, (int64_t)a.carry_len, (int64_t)a.nsamp };
         cf2 coef[4][P / 2];
 #pragma unroll
@@ -505,52 +582,108 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
         }
         chz_load_half_ring<P, 0, P, false>(ring, in, fs, t);
         chz_load_half_ring<P, 0, P + 2, false>(ring, in, fs + NB, t);
-        __syncthreads();                                          // all roles start together
+        __syncthreads();                                          // all roles start together 
         // one half-step = four frames: fold them, then load the frames of the half-step after next into the two slots that
         // just died.  A load has eight frames (~3 us) to arrive: with four frames of lead the fold waves were the critical path
         // (4 waves x 8 loads x 512 B = 16 KB in flight per CU do not cover the HBM latency under load).
-        auto half_step = [&](auto basec, int h) {
+        // One half-step = four frames.  EDGE half-steps (the head of a launch, where the inputs still come from the carry of the
+        // previous push, and pushes shorter than a frame) load with ordinary, bounds-checked loads BEHIND the fold and drain them
+        // at once; all others prefetch with untracked asm loads (chz_load1_ring) that go into the ring slots as they die, as early
+        // in the step as possible: the oldest slot of branches 0, 1 is not read at all in this half-step; the oldest of branches
+        // 2, 3 and the second-oldest of branches 0, 1 are last read by the first tap block of frames 0 / 1; the second-oldest of
+        // branches 2, 3 by the first tap block of frame 2.  A load then has almost two time steps to land and is issued beside the
+        // other roles' VALU work.  The two kinds never meet inside one loop body: a control-flow join behind an untracked load
+        // invites the compiler to copy a register whose load is still in flight (it did; tests/test_cpu_inflight_loads.py scans
+        // the assembly for that).
+        auto half_step = [&](auto basec, auto edgec, int h) {
             constexpr int BASE = decltype(basec)::value;
-            if (h < nh) {
+            constexpr bool EDGE = decltype(edgec)::value;
+            CHZ_STAMP(h, 0);
+            if (__builtin_expect(h < nh, 1)) {
                 const int64_t F = fs + (int64_t)NB * h;
                 cf2 *dst = buf + (h & (CHZ_SLOTS - 1)) * NB * CHZ_FB;
                 chz_ring_wait<P, BASE>(ring);
-                chz_fold_half_ring<P, BASE>(ring, coef, tw1, dst, t);
-                if (in.batch_in_block(F + 2 * NB)) chz_load_half_ring<P, BASE, P + 4, true>(ring, in, F + 2 * NB, t);
-                else chz_load_half_ring<P, BASE, P + 4, false>(ring, in, F + 2 * NB, t);   // generic: zero beyond the data
+                CHZ_STAMP(h, 1);
+#ifndef CHZ_SKIP_FOLD
+                if constexpr (EDGE) {
+                    chz_fold2_ring<P, BASE, 0>(ring, coef, tw1, dst, t, [] {});
+                    chz_fold2_ring<P, BASE, 2>(ring, coef, tw1, dst, t, [] {});
+                    chz_load_half_ring<P, BASE, P + 4, false>(ring, in, F + 2 * NB, t);
+                } else {
+                    chz_load1_ring<P, BASE, P + 4, 0, true>(ring, in, F + 2 * NB, t);
+                    chz_fold2_ring<P, BASE, 0>(ring, coef, tw1, dst, t, [&] {
+                        chz_load1_ring<P, BASE, P + 4, 1, true>(ring, in, F + 2 * NB, t);
+                        chz_load1_ring<P, BASE, P + 4, 2, true>(ring, in, F + 2 * NB, t);
+                    });
+                    chz_fold2_ring<P, BASE, 2>(ring, coef, tw1, dst, t, [&] { chz_load1_ring<P, BASE, P + 4, 3, true>(ring, in, F + 2 * NB, t); });
+                }
+#endif
+                CHZ_STAMP(h, 2);
             }
+            CHZ_STAMP(h, 3);
             __syncthreads();
+            CHZ_STAMP(h, 4);
         };
         constexpr int PERIOD = (P + 4) / 2;                       // half-steps until the ring is back where it started (6)
         static_assert(PERIOD == 6, "the unrolled loop below is written for P = 8");
-        for (int h = 0; h < nsteps; h += PERIOD) {
-            half_step(std::integral_constant<int, 0>{}, h);
-            if (h + 1 >= nsteps) break;
-            half_step(std::integral_constant<int, 2>{}, h + 1);
-            if (h + 2 >= nsteps) break;
-            half_step(std::integral_constant<int, 4>{}, h + 2);
-            if (h + 3 >= nsteps) break;
-            half_step(std::integral_constant<int, 6>{}, h + 3);
-            if (h + 4 >= nsteps) break;
-            half_step(std::integral_constant<int, 8>{}, h + 4);
-            if (h + 5 >= nsteps) break;
-            half_step(std::integral_constant<int, 10>{}, h + 5);
+        auto run_steps = [&](auto edgec, int hb, int he) {        // half-steps [hb, he); hb is a multiple of the ring's period
+            for (int h = hb; h < he; h += PERIOD) {
+                half_step(std::integral_constant<int, 0>{}, edgec, h);
+                if (h + 1 >= he) break;
+                half_step(std::integral_constant<int, 2>{}, edgec, h + 1);
+                if (h + 2 >= he) break;
+                half_step(std::integral_constant<int, 4>{}, edgec, h + 2);
+                if (h + 3 >= he) break;
+                half_step(std::integral_constant<int, 6>{}, edgec, h + 3);
+                if (h + 4 >= he) break;
+                half_step(std::integral_constant<int, 8>{}, edgec, h + 4);
+                if (h + 5 >= he) break;
+                half_step(std::integral_constant<int, 10>{}, edgec, h + 5);
+            }
+        };
+        // half-step h loads the frames of half-step h + 2: the fast loader is right once those lie inside the new block
+        int h_edge = 0;
+        if (in.nsamp < CHZ_D) h_edge = nsteps;
+        else if ((fs + 2 * NB) * D < in.lead) {
+            const int64_t need = (in.lead + D - 1) / D - (fs + 2 * NB);           // frames from the first loaded one to the first inside the block
+            h_edge = (int)((need + NB - 1) / NB);
+            h_edge = (h_edge + PERIOD - 1) / PERIOD * PERIOD;
+            if (h_edge > nsteps) h_edge = nsteps;
         }
-    } else if (wave < 8) {
-        // ------------------------------------------------------------------ pass-2 role
-        const int wf = wave - 4;                                  // frame of the half-batch this wave transforms
-        __syncthreads();                                          // all roles start together
-        for (int i = 0; i < nsteps; i++) {
-            const int h = i - 1;
-            if (h >= 0 && h < nh) chz_p2(buf + ((h & (CHZ_SLOTS - 1)) * NB + wf) * CHZ_FB, lane);
-            __syncthreads();
+        run_steps(std::true_type{}, 0, h_edge);
+        run_steps(std::false_type{}, h_edge, nsteps);
+        CHZ_TL_FLUSH;
+    } else if (role == 1) {
+        // ------------------------------------------------------------------ pass-2 role (+ pass 3 when P3_WITH_P2)
+        cf2 tw2[15];                                              // (CHZ_TW2 = 1) pass 2's input twiddles W_64^{r k}, k = lane & 3
+#pragma unroll
+        for (int r = 1; r < 16; r++) tw2[r - 1] = chz_twiddle(r * (lane & 3), 64);
+        cf2 tw3[P3_WITH_P2 ? 15 : 1];                             // twiddles of the second radix-16 pass: W_1024^{r lane}
+        if constexpr (P3_WITH_P2) {
+#pragma unroll
+            for (int r = 1; r < 16; r++) tw3[r - 1] = chz_twiddle(r * lane, 1024);
         }
+        __syncthreads();                                          // all roles start together 
+        {
+            for (int i = 0; i < nh + 3; i++) {
+                const int h = i - 1, h3 = i - 2;
+                CHZ_STAMP(i, 0);
+                if (h >= 0 && h < nh) chz_p2(buf + ((h & (CHZ_SLOTS - 1)) * NB + wf) * CHZ_FB, lane, tw2);
+                CHZ_STAMP(i, 1);
+                if constexpr (P3_WITH_P2) { if (h3 >= 0 && h3 < nh) chz_p3(buf + ((h3 & (CHZ_SLOTS - 1)) * NB + wf) * CHZ_FB, tw3, lane); }
+                CHZ_STAMP(i, 3);
+                __syncthreads();
+                CHZ_STAMP(i, 4);
+            }
+        }
+        CHZ_TL_FLUSH;
     } else {
         // ------------------------------------------------------------------ pass-3 + slicer role
-        const int wf = wave - 8;                                  // frame of the half-batch this wave transforms
-        cf2 tw3[15];                                              // twiddles of the second radix-16 pass: W_1024^{r lane}
+        cf2 tw3[P3_WITH_P2 ? 1 : 15];                             // twiddles of the second radix-16 pass: W_1024^{r lane}
+        if constexpr (!P3_WITH_P2) {
 #pragma unroll
-        for (int r = 1; r < 16; r++) tw3[r - 1] = chz_twiddle(r * lane, 1024);
+            for (int r = 1; r < 16; r++) tw3[r - 1] = chz_twiddle(r * lane, 1024);
+        }
         // Bin ownership: pair j of (wave w, lane l) holds bins 512 j + 128 w + l and + 64: one block of the planar layout, so the
         // four floats a frame brings for a pair sit at base + {0, 64, 128, 192} (two ds_read2st64_b32), consecutive lanes read
         // consecutive floats, and the register pairs are (re, re) and (im, im) of the two channels.  A pair-wave whose 128
@@ -569,86 +702,97 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
         uint32_t hold[2][2][4] = {};                              // finished ring words of the four channels waiting for their 16-byte store
         int nheld = 0;
         const uint64_t mask32 = 2ull * a.ring_words - 1;
-        __syncthreads();                                          // all roles start together
-        for (int i = 0; i < nsteps; i++) {
-            const int hs = i - 3, h3 = i - 2;
-            if (hs >= 0 && hs < nh) {
-                const int64_t F = fs + (int64_t)NB * hs;          // first frame of the half-batch (multiple of 4)
-                const float *Af = (const float *)(buf + (hs & (CHZ_SLOTS - 1)) * NB * CHZ_FB);
+        auto slice_half = [&](int hs) {
+#ifdef CHZ_SKIP_SLICER
+            return;
+#endif                           // the four frames of half-batch hs: slice (or, unfused, store) this lane's bins
+            const int64_t F = fs + (int64_t)NB * hs;          // first frame of the half-batch (multiple of 4)
+            const float *Af = (const float *)(buf + (hs & (CHZ_SLOTS - 1)) * NB * CHZ_FB);
 #pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    if (!pair_on[j]) continue;
-                    f2 yr[NB], yi[NB];
+            for (int j = 0; j < 2; j++) {
+                if (!pair_on[j]) continue;
+                f2 yr[NB], yi[NB];
 #pragma unroll
-                    for (int g = 0; g < NB; g++) {
-                        const float *q = Af + pbase + g * CHZ_FBF + 1024 * j;
-                        yr[g] = (f2){ q[0], q[64] };
-                        yi[g] = (f2){ q[128], q[192] };
-                    }
-                    if constexpr (IQ) {
-                        // four frames of a bin leave as one 32-byte run of the channel-major block
-                        const int ng = (int)(f1 - F < (int64_t)NB ? f1 - F : (int64_t)NB);
+                for (int g = 0; g < NB; g++) {
+                    const float *q = Af + pbase + g * CHZ_FBF + 1024 * j;
+                    yr[g] = (f2){ q[0], q[64] };
+                    yi[g] = (f2){ q[128], q[192] };
+                }
+                if constexpr (IQ) {
+                    // four frames of a bin leave as one 32-byte run of the channel-major block
+                    const int ng = (int)(f1 - F < (int64_t)NB ? f1 - F : (int64_t)NB);
 #pragma unroll
-                        for (int e = 0; e < 2; e++) {
-                            if (ch[j][e] < a.n_channels) {
-                                float2 *dstp = a.out + (uint64_t)ch[j][e] * a.ld + F;
-                                if (ng == NB) {
+                    for (int e = 0; e < 2; e++) {
+                        if (ch[j][e] < a.n_channels) {
+                            float2 *dstp = a.out + (uint64_t)ch[j][e] * a.ld + F;
+                            if (ng == NB) {
 #pragma unroll
-                                    for (int g = 0; g < NB; g += 2)
-                                        *(float4 *)(dstp + g) = make_float4(yr[g][e], yi[g][e], yr[g + 1][e], yi[g + 1][e]);
-                                } else {
+                                for (int g = 0; g < NB; g += 2)
+                                    *(float4 *)(dstp + g) = make_float4(yr[g][e], yi[g][e], yr[g + 1][e], yi[g + 1][e]);
+                            } else {
 #pragma unroll
-                                    for (int g = 0; g < NB; g++)
-                                        if (g < ng) dstp[g] = make_float2(yr[g][e], yi[g][e]);
-                                }
+                                for (int g = 0; g < NB; g++)
+                                    if (g < ng) dstp[g] = make_float2(yr[g][e], yi[g][e]);
                             }
                         }
-                    } else {
+                    }
+                } else {
 #pragma unroll
-                        for (int g = 0; g < NB; g++) { if (g & 1) S[j].template step<1>(yr[g], yi[g]); else S[j].template step<0>(yr[g], yi[g]); }
-                    }
+                    for (int g = 0; g < NB; g++) { if (g & 1) S[j].template step<1>(yr[g], yi[g]); else S[j].template step<0>(yr[g], yi[g]); }
                 }
-                if constexpr (!IQ) {
-                    if (a.stream_start && F < 0) {                // frames before the stream are exactly +0 (the FFT of zeros may hold -0):
-                        asm volatile("" ::: "memory");            // the state they leave is that of a fresh stream (a real branch, twice per launch)
-                        S[0].reset(); S[1].reset();
-                    }
-                    if (F >= f0 && ((F + NB - 1) & 31) == 31) {   // 32 real frames collected (f0 is a multiple of 64)
-                        // A channel's words leave as ONE 16-byte store per 128 frames (aligned group of four ring dwords): single
-                        // dwords scattered over the channels' ring rows are counted -- and written -- as 32-byte sectors, 8x the 27 MB
-                        // of slicer bits per GiB of input (round 1: 215 MB of 1.36 GB traffic).  Ranges start and end on 64-frame
-                        // boundaries, so a run that is not a whole group is exactly two words.
-                        const uint64_t w = (a.n_done + (uint64_t)(F + NB - 1)) >> 5;   // absolute ring dword of the finished word
-                        const bool last = F + NB >= f1;
+            }
+            if constexpr (!IQ) {
+                if (a.stream_start && F < 0) {                // frames before the stream are exactly +0 (the FFT of zeros may hold -0):
+                    asm volatile("" ::: "memory");            // the state they leave is that of a fresh stream (a real branch, twice per launch)
+                    S[0].reset(); S[1].reset();
+                }
+                if (F >= f0 && ((F + NB - 1) & 31) == 31) {   // 32 real frames collected (f0 is a multiple of 64)
+                    // A channel's words leave as ONE 16-byte store per 128 frames (aligned group of four ring dwords): single
+                    // dwords scattered over the channels' ring rows are counted -- and written -- as 32-byte sectors, 8x the 27 MB
+                    // of slicer bits per GiB of input (round 1: 215 MB of 1.36 GB traffic).  Ranges start and end on 64-frame
+                    // boundaries, so a run that is not a whole group is exactly two words.
+                    const uint64_t w = (a.n_done + (uint64_t)(F + NB - 1)) >> 5;   // absolute ring dword of the finished word
+                    const bool last = F + NB >= f1;
+#pragma unroll
+                    for (int j = 0; j < 2; j++)
+#pragma unroll
+                        for (int e = 0; e < 2; e++) {
+                            uint32_t word = S[j].word(e);
+                            if (SL == AMPS_SLICER_PRODUCT && a.stream_start && F + NB - 1 == 31) word |= 7u;   // no partner yet: g = 1
+                            hold[j][e][0] = hold[j][e][1]; hold[j][e][1] = hold[j][e][2]; hold[j][e][2] = hold[j][e][3]; hold[j][e][3] = word;
+                        }
+                    nheld++;
+                    if ((w & 3) == 3 || last) {
 #pragma unroll
                         for (int j = 0; j < 2; j++)
 #pragma unroll
                             for (int e = 0; e < 2; e++) {
-                                uint32_t word = S[j].word(e);
-                                if (SL == AMPS_SLICER_PRODUCT && a.stream_start && F + NB - 1 == 31) word |= 7u;   // no partner yet: g = 1
-                                hold[j][e][0] = hold[j][e][1]; hold[j][e][1] = hold[j][e][2]; hold[j][e][2] = hold[j][e][3]; hold[j][e][3] = word;
-                            }
-                        nheld++;
-                        if ((w & 3) == 3 || last) {
-#pragma unroll
-                            for (int j = 0; j < 2; j++)
-#pragma unroll
-                                for (int e = 0; e < 2; e++) {
-                                    if (ch[j][e] < a.n_channels) {
-                                        uint32_t *row = (uint32_t *)(a.gring + (uint64_t)ch[j][e] * a.ring_words);
-                                        if (nheld == 4 && (w & 3) == 3) *(uint4 *)(row + ((w - 3) & mask32)) = make_uint4(hold[j][e][0], hold[j][e][1], hold[j][e][2], hold[j][e][3]);
-                                        else if (nheld == 2) *(uint2 *)(row + ((w - 1) & mask32)) = make_uint2(hold[j][e][2], hold[j][e][3]);
-                                        else for (int k = 0; k < nheld; k++) row[(w - (uint64_t)(nheld - 1 - k)) & mask32] = hold[j][e][4 - nheld + k];   // not reached: ranges are multiples of 64 frames
-                                    }
+                                if (ch[j][e] < a.n_channels) {
+                                    uint32_t *row = (uint32_t *)(a.gring + (uint64_t)ch[j][e] * a.ring_words);
+                                    if (nheld == 4 && (w & 3) == 3) *(uint4 *)(row + ((w - 3) & mask32)) = make_uint4(hold[j][e][0], hold[j][e][1], hold[j][e][2], hold[j][e][3]);
+                                    else if (nheld == 2) *(uint2 *)(row + ((w - 1) & mask32)) = make_uint2(hold[j][e][2], hold[j][e][3]);
+                                    else for (int k = 0; k < nheld; k++) row[(w - (uint64_t)(nheld - 1 - k)) & mask32] = hold[j][e][4 - nheld + k];   // not reached: ranges are multiples of 64 frames
                                 }
-                            nheld = 0;
-                        }
+                            }
+                        nheld = 0;
                     }
                 }
             }
-            if (h3 >= 0 && h3 < nh) chz_p3(buf + ((h3 & (CHZ_SLOTS - 1)) * NB + wf) * CHZ_FB, tw3, lane);
-            __syncthreads();
+        };
+        __syncthreads();                                          // all roles start together 
+        {
+            for (int i = 0; i < nh + 3; i++) {
+                const int hs = i - 3, h3 = i - 2;
+                CHZ_STAMP(i, 0);
+                if (hs >= 0 && hs < nh) slice_half(hs);
+                CHZ_STAMP(i, 1);
+                if constexpr (!P3_WITH_P2) { if (h3 >= 0 && h3 < nh) chz_p3(buf + ((h3 & (CHZ_SLOTS - 1)) * NB + wf) * CHZ_FB, tw3, lane); }
+                CHZ_STAMP(i, 3);
+                __syncthreads();
+                CHZ_STAMP(i, 4);
+            }
         }
+        CHZ_TL_FLUSH;
     }
 }
 
@@ -799,6 +943,9 @@ inline int channelizer_run(ChannelizerState &z, const float2 *iq, size_t nsamp, 
     // (whole words of the RECC bit ring); the rest waits in the carry
     const uint32_t nframes = (uint32_t)(avail / CHZ_D) & (fused ? ~63u : ~1u);
     if (nframes > z.max_frames) return -E2BIG;
+#ifdef CHZ_TIMELINE
+    unsigned long long *a_tl_last = nullptr;
+#endif
     if (nframes) {
         ChzArgs a{};
         a.block = d; a.carry = z.carry[z.carry_cur]; a.taps = z.taps; a.out = z.out; a.ld = z.ld;
@@ -812,12 +959,27 @@ inline int channelizer_run(ChannelizerState &z, const float2 *iq, size_t nsamp, 
         a.gring = gring; a.ring_words = ring_words; a.n_done = n_done;
         a.stream_start = z.frames_done == 0 ? 1u : 0u;
         const dim3 g12((nframes + fpw - 1) / fpw), b12(768);
+#ifdef CHZ_TIMELINE
+        static unsigned long long *tl_dev = nullptr;
+        constexpr size_t TLN = 12 * 8;
+        if (!tl_dev && hipMalloc((void **)&tl_dev, TLN * 8) != hipSuccess) return -ENOMEM;
+        (void)hipMemsetAsync(tl_dev, 0, TLN * 8, s);
+        a.tl = tl_dev;
+        a_tl_last = tl_dev;
+#endif
         if (!fused) hipLaunchKernelGGL((chz12_kernel<8, CHZ12_IQ>), g12, b12, 0, s, a);
         else if (slicer == AMPS_SLICER_PRODUCT) hipLaunchKernelGGL((chz12_kernel<8, AMPS_SLICER_PRODUCT>), g12, b12, 0, s, a);
         else if (slicer == AMPS_SLICER_SINE) hipLaunchKernelGGL((chz12_kernel<8, AMPS_SLICER_SINE>), g12, b12, 0, s, a);
         else hipLaunchKernelGGL((chz12_kernel<8, AMPS_SLICER_ATAN_BOXCAR>), g12, b12, 0, s, a);
     }
     if (after_main) after_main(after_ctx);                            // timing: the span ends behind the filter-bank kernel, before the carry copy
+#ifdef CHZ_TIMELINE
+    if (const char *path = std::getenv("AMPS_RECC_CHZ_TIMELINE")) {       // the last launch's stamps, raw
+        std::vector<unsigned long long> tl(12 * 8);
+        if (a_tl_last && hipStreamSynchronize(s) == hipSuccess && hipMemcpy(tl.data(), a_tl_last, tl.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
+            if (FILE *f = std::fopen(path, "wb")) { std::fwrite(tl.data(), 8, tl.size(), f); std::fclose(f); }
+    }
+#endif
     const uint32_t consumed = nframes * CHZ_D;                        // virtual samples consumed (incl. leftover)
     const uint32_t new_left = (uint32_t)(avail - consumed);
     hipLaunchKernelGGL(chz_carry_kernel, dim3((hist + new_left + 255) / 256), dim3(256), 0, s, d, z.carry[z.carry_cur],
