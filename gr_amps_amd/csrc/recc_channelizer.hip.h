@@ -137,9 +137,6 @@ __device__ __forceinline__ cf2 fma_hi(cf2 a, cf2 c, cf2 s)
 
 // ---- frame geometry ----
 // A half-batch = four frames (what the fold role produces per time step); a frame buffer holds one 1024-point frame.
-#ifndef CHZ_TW2
-#define CHZ_TW2 0                                              // who applies pass 2's input twiddles: 0 the fold role, 1 the pass-2 role (experiment)
-#endif
 constexpr int CHZ_BATCH = 4;
 constexpr int CHZ_FB = CHZ_M + CHZ_M / 16;                     // padded frame buffer, cf2 elements
 constexpr int CHZ_FBF = 2 * CHZ_FB;                            // ... in floats
@@ -178,23 +175,14 @@ static_assert(chz_pos1(255, 3) < CHZ_FB && chz_pos2(1023) < CHZ_FB && chz_planar
 // X = DFT16(u), A[16 (i - k) + k + 4 r] = X[r].  The input twiddles W_64^{r k} have already been applied by the fold role
 // (chz_fold2_ring): read from an LDS table here, one pair at a time between the multiplies, they cost eight exposed LDS
 // latencies per pass (measured with s_memtime: 2950 cycles per frame against 1780 for pass 3).
-__device__ __forceinline__ void chz_p2(cf2 *A, int lane, const cf2 (&tw2)[15])
+__device__ __forceinline__ void chz_p2(cf2 *A, int lane)
 {
-#ifdef CHZ_SKIP_FFT
-    return;
-#endif
     const int k = lane & 3;
     cf2 u[16];
     // pass 1 left element 4 t + k1 at chz_pos1(t, k1): lane i wants 4 t + k1 = i + 64 r, i.e. t = (i >> 2) + 16 r, k1 = i & 3
     const cf2 *src = A + chz_pos1(lane >> 2, k);
 #pragma unroll
     for (int r = 0; r < 16; r++) u[r] = src[16 * r];
-#if CHZ_TW2 == 1
-#pragma unroll
-    for (int r = 1; r < 16; r++) u[r] = cmul(u[r], tw2[r - 1]);
-#else
-    (void)tw2;
-#endif
     // DFT16 = 4 x DFT4 over a (s = 4a + b), twiddle W16^{bc}, 4 x DFT4 over b -> X[c + 4d]
     cf2 v[4][4];
 #pragma unroll
@@ -227,9 +215,6 @@ template <int NT>
 __device__ __forceinline__ void chz_p3(cf2 *A, const cf2 (&tw)[NT], int lane)
 {
     static_assert(NT == 15 || NT == 1, "fifteen twiddles (NT = 1: the role that does not run pass 3)");
-#ifdef CHZ_SKIP_FFT
-    return;
-#endif
     if constexpr (NT == 15) {
     cf2 u[16];
     const cf2 *src = A + lane;                                  // chz_pos2(lane + 64 r) = lane + 68 r
@@ -369,12 +354,7 @@ __device__ __forceinline__ void chz_fold2_ring(const cf2 (&ring)[4][P + 4], cons
         // the input twiddles of pass 2 (element 4 t + k1 is its point r = t >> 4 of lane 4 (t & 15) + k1: W_64^{r k1}) are applied
         // HERE: the fold waves wait at the barriers more than half of the time, the FFT waves are the critical path of a time step
         cf2 *d = bufA + (FA + f) * CHZ_FB + t;
-#if CHZ_TW2 == 0
         d[chz_pos1(0, 0)] = o[0]; d[chz_pos1(0, 1)] = cmul(o[1], tw1[0]); d[chz_pos1(0, 2)] = cmul(o[2], tw1[1]); d[chz_pos1(0, 3)] = cmul(o[3], tw1[2]);
-#else
-        (void)tw1;
-        d[chz_pos1(0, 0)] = o[0]; d[chz_pos1(0, 1)] = o[1]; d[chz_pos1(0, 2)] = o[2]; d[chz_pos1(0, 3)] = o[3];
-#endif
     }
 }
 // The two samples frame F + G brings for this thread go to branches 2 (G & 1) + {0, 1}, logical element ELEM + (G >> 1).
@@ -498,6 +478,32 @@ template <int SL> struct ChzSlicePair {
             pr = yr; pi = yi;
         }
     }
+    // the four frames of a half-batch (frame 0 has even parity).  Spec A: the four arctangents are independent of the stream
+    // state, so they are evaluated in lock step (fm_phase_planar_n) before the sequential boxcar / slicer part
+    __device__ __forceinline__ void step4(const f2 (&yr)[4], const f2 (&yi)[4])
+    {
+        if constexpr (SL == AMPS_SLICER_ATAN_BOXCAR) {
+            f2 re[4], im[4], d[4];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const f2 qr = g ? yr[g - 1] : pr, qi = g ? yi[g - 1] : pi;
+                re[g] = __builtin_elementwise_fma(yr[g], qr, yi[g] * qi);                                   // y conj(prev)
+                im[g] = __builtin_elementwise_fma(yi[g], qr, -(yr[g] * qi));
+            }
+            fm_phase_planar_n<4>(re, im, d);
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const f2 s = (g & 1) == 0 ? (d2 + d1) + d[g] : d2 + (d1 + d[g]);
+                gw[0] = __builtin_amdgcn_alignbit(s.x >= 0.0f ? 1u : 0u, gw[0], 1);
+                gw[1] = __builtin_amdgcn_alignbit(s.y >= 0.0f ? 1u : 0u, gw[1], 1);
+                d2 = d1; d1 = d[g];
+            }
+            pr = yr[3]; pi = yi[3];
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; g++) { if (g & 1) step<1>(yr[g], yi[g]); else step<0>(yr[g], yi[g]); }
+        }
+    }
     __device__ __forceinline__ uint32_t word(int e) const { return SL == AMPS_SLICER_ATAN_BOXCAR ? gw[e] : ~__builtin_bitreverse32(gw[e]); }
 };
 
@@ -528,26 +534,16 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
     const int lane = tid & 63;
     // Role of a wave.  The hardware arbitrates VALU issue between the waves of a SIMD by priority, then by age: the fold role is
     // pure VALU and would starve the two roles that alternate LDS round trips with short VALU bursts -- their latency chains
-    // would then run AFTER the fold instead of beside it (measured: 0.45 ms per GiB with the fold in the oldest waves and no
-    // priorities, against 0.38 for round 2's kernel).  So the latency-bound roles get the oldest waves and a higher priority.
-#ifndef CHZ_ORDER
-#define CHZ_ORDER 1
-#endif
-#ifndef CHZ_PRIO
-#define CHZ_PRIO 1
-#endif
-    const int role = CHZ_ORDER == 0 ? wave >> 2 : 2 - (wave >> 2);      // 0 fold, 1 pass 2, 2 pass 3 + slicer
-    // Which role runs pass 3.  Behind the cheap slicers (specs B, C: ~7 instructions per channel pair and frame) it shares the
-    // slicer's waves; spec A's arctangent makes the slicer the longest chain of a time step (~90 instructions per pair and
-    // frame, serial Newton / Horner chains), so there pass 3 moves to the pass-2 waves.
-#ifndef CHZ_SPLIT
-#define CHZ_SPLIT 1
-#endif
-    constexpr bool P3_WITH_P2 = CHZ_SPLIT == 2 || (CHZ_SPLIT == 1 && !IQ && SL == AMPS_SLICER_ATAN_BOXCAR);
+    // would then run AFTER the fold instead of beside it.  So the latency-bound roles get the oldest waves and a higher priority
+    // (measured, ms per GiB, spec C / A: fold in the oldest waves and no priorities 0.440 / 0.592; priorities alone 0.390 /
+    // 0.505; order alone 0.395 / 0.502; both 0.387 / 0.503; round 2's two-role kernel on the same box 0.387 / 0.532).
+    const int role = 2 - (wave >> 2);                                   // 0 fold (waves 8..11), 1 pass 2 (4..7), 2 pass 3 + slicer (0..3)
+    // Which role runs pass 3.  Behind the cheap slicers (specs B, C: 7 instructions per channel pair and frame) it shares the
+    // slicer's waves; spec A's arctangent makes the slicer the longest chain of a time step (46 instructions per pair and
+    // frame), so there pass 3 moves to the pass-2 waves (spec A 0.537 -> 0.517 ms, spec C 0.399 -> 0.414 if it moved too).
+    constexpr bool P3_WITH_P2 = !IQ && SL == AMPS_SLICER_ATAN_BOXCAR;
     const int wf = wave & 3;                                            // frame of a half-batch this wave transforms (roles 1, 2)
-    if (CHZ_PRIO == 1) { if (role == 2) __builtin_amdgcn_s_setprio(2); else if (role == 1) __builtin_amdgcn_s_setprio(1); }
-    if (CHZ_PRIO == 2) { if (role != 0) __builtin_amdgcn_s_setprio(1); }
-    if (CHZ_PRIO == 3) { if (role == 1) __builtin_amdgcn_s_setprio(2); else if (role == 2) __builtin_amdgcn_s_setprio(1); }
+    if (role == 2) __builtin_amdgcn_s_setprio(2); else if (role == 1) __builtin_amdgcn_s_setprio(1);
     const int64_t f0 = (int64_t)blockIdx.x * a.frames_per_wg;   // multiple of 64
     if (f0 >= (int64_t)a.nframes) return;
     int64_t f1 = f0 + a.frames_per_wg; if (f1 > (int64_t)a.nframes) f1 = a.nframes;
@@ -604,7 +600,6 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
                 cf2 *dst = buf + (h & (CHZ_SLOTS - 1)) * NB * CHZ_FB;
                 chz_ring_wait<P, BASE>(ring);
                 CHZ_STAMP(h, 1);
-#ifndef CHZ_SKIP_FOLD
                 if constexpr (EDGE) {
                     chz_fold2_ring<P, BASE, 0>(ring, coef, tw1, dst, t, [] {});
                     chz_fold2_ring<P, BASE, 2>(ring, coef, tw1, dst, t, [] {});
@@ -617,7 +612,6 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
                     });
                     chz_fold2_ring<P, BASE, 2>(ring, coef, tw1, dst, t, [&] { chz_load1_ring<P, BASE, P + 4, 3, true>(ring, in, F + 2 * NB, t); });
                 }
-#endif
                 CHZ_STAMP(h, 2);
             }
             CHZ_STAMP(h, 3);
@@ -655,9 +649,6 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
         CHZ_TL_FLUSH;
     } else if (role == 1) {
         // ------------------------------------------------------------------ pass-2 role (+ pass 3 when P3_WITH_P2)
-        cf2 tw2[15];                                              // (CHZ_TW2 = 1) pass 2's input twiddles W_64^{r k}, k = lane & 3
-#pragma unroll
-        for (int r = 1; r < 16; r++) tw2[r - 1] = chz_twiddle(r * (lane & 3), 64);
         cf2 tw3[P3_WITH_P2 ? 15 : 1];                             // twiddles of the second radix-16 pass: W_1024^{r lane}
         if constexpr (P3_WITH_P2) {
 #pragma unroll
@@ -668,7 +659,7 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
             for (int i = 0; i < nh + 3; i++) {
                 const int h = i - 1, h3 = i - 2;
                 CHZ_STAMP(i, 0);
-                if (h >= 0 && h < nh) chz_p2(buf + ((h & (CHZ_SLOTS - 1)) * NB + wf) * CHZ_FB, lane, tw2);
+                if (h >= 0 && h < nh) chz_p2(buf + ((h & (CHZ_SLOTS - 1)) * NB + wf) * CHZ_FB, lane);
                 CHZ_STAMP(i, 1);
                 if constexpr (P3_WITH_P2) { if (h3 >= 0 && h3 < nh) chz_p3(buf + ((h3 & (CHZ_SLOTS - 1)) * NB + wf) * CHZ_FB, tw3, lane); }
                 CHZ_STAMP(i, 3);
@@ -702,10 +693,7 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
         uint32_t hold[2][2][4] = {};                              // finished ring words of the four channels waiting for their 16-byte store
         int nheld = 0;
         const uint64_t mask32 = 2ull * a.ring_words - 1;
-        auto slice_half = [&](int hs) {
-#ifdef CHZ_SKIP_SLICER
-            return;
-#endif                           // the four frames of half-batch hs: slice (or, unfused, store) this lane's bins
+        auto slice_half = [&](int hs) {                           // the four frames of half-batch hs: slice (or, unfused, store) this lane's bins
             const int64_t F = fs + (int64_t)NB * hs;          // first frame of the half-batch (multiple of 4)
             const float *Af = (const float *)(buf + (hs & (CHZ_SLOTS - 1)) * NB * CHZ_FB);
 #pragma unroll
@@ -737,8 +725,7 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
                         }
                     }
                 } else {
-#pragma unroll
-                    for (int g = 0; g < NB; g++) { if (g & 1) S[j].template step<1>(yr[g], yi[g]); else S[j].template step<0>(yr[g], yi[g]); }
+                    S[j].step4(yr, yi);
                 }
             }
             if constexpr (!IQ) {

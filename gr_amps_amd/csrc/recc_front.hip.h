@@ -140,6 +140,78 @@ __device__ __forceinline__ f2 fm_phase_planar(f2 re, f2 im)
     a.y = re.y < 0.0f ? a_reflect.y : a.y;
     return (f2){ __builtin_copysignf(a.x, im.x), __builtin_copysignf(a.y, im.y) };
 }
+// N independent planar evaluations written in lock step (same operations, same order per value, so every result is
+// bit-identical to a separate fm_phase_planar call): the Newton and Horner chains are serial and every packed operation that
+// consumes the previous one costs a wait state, so one chain at a time runs at a third of the issue rate (the compiler keeps
+// the source order: it pads the single chain with s_nop instead of interleaving)
+// an empty asm that "uses and redefines" the N values of one row: every chain has reached this row before any goes on
+template <int N> __device__ __forceinline__ void fm_row_join(f2 (&v)[N])
+{
+    static_assert(N == 4 || N == 2, "rows of two or four");
+    if constexpr (N == 4) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+    else asm volatile("" : "+v"(v[0]), "+v"(v[1]));
+}
+template <int N>
+__device__ __forceinline__ void fm_phase_planar_n(const f2 (&re)[N], const f2 (&im)[N], f2 (&out)[N])
+{
+    f2 mx[N], mn[N], r[N], e[N], q[N], z[N], p[N], a[N];
+    bool sw[N][2];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const float axa = __builtin_fabsf(re[i].x), aya = __builtin_fabsf(im[i].x), axb = __builtin_fabsf(re[i].y), ayb = __builtin_fabsf(im[i].y);
+        mx[i] = (f2){ __builtin_fmaxf(__builtin_fmaxf(axa, aya), AMPS_MX_FLOOR), __builtin_fmaxf(__builtin_fmaxf(axb, ayb), AMPS_MX_FLOOR) };
+        mn[i] = (f2){ __builtin_fminf(axa, aya), __builtin_fminf(axb, ayb) };
+        sw[i][0] = aya > axa; sw[i][1] = ayb > axb;
+        r[i] = (f2){ __uint_as_float(AMPS_RCP_MAGIC - __float_as_uint(mx[i].x)), __uint_as_float(AMPS_RCP_MAGIC - __float_as_uint(mx[i].y)) };
+    }
+    const f2 one = { 1.0f, 1.0f };
+#pragma unroll
+    for (int it = 0; it < 3; it++) {
+#pragma unroll
+        for (int i = 0; i < N; i++) e[i] = __builtin_elementwise_fma(-mx[i], r[i], one);
+    fm_row_join(e);
+#pragma unroll
+        for (int i = 0; i < N; i++) r[i] = __builtin_elementwise_fma(r[i], e[i], r[i]);
+    fm_row_join(r);
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) q[i] = mn[i] * r[i];
+    fm_row_join(q);
+#pragma unroll
+    for (int i = 0; i < N; i++) z[i] = q[i] * q[i];
+    fm_row_join(z);
+#pragma unroll
+    for (int i = 0; i < N; i++) p[i] = __builtin_elementwise_fma((f2){ AMPS_ATAN_C5, AMPS_ATAN_C5 }, z[i], (f2){ AMPS_ATAN_C4, AMPS_ATAN_C4 });
+    fm_row_join(p);
+#pragma unroll
+    for (int i = 0; i < N; i++) p[i] = __builtin_elementwise_fma(p[i], z[i], (f2){ AMPS_ATAN_C3, AMPS_ATAN_C3 });
+    fm_row_join(p);
+#pragma unroll
+    for (int i = 0; i < N; i++) p[i] = __builtin_elementwise_fma(p[i], z[i], (f2){ AMPS_ATAN_C2, AMPS_ATAN_C2 });
+    fm_row_join(p);
+#pragma unroll
+    for (int i = 0; i < N; i++) p[i] = __builtin_elementwise_fma(p[i], z[i], (f2){ AMPS_ATAN_C1, AMPS_ATAN_C1 });
+    fm_row_join(p);
+#pragma unroll
+    for (int i = 0; i < N; i++) p[i] = __builtin_elementwise_fma(p[i], z[i], (f2){ AMPS_ATAN_C0, AMPS_ATAN_C0 });
+    fm_row_join(p);
+#pragma unroll
+    for (int i = 0; i < N; i++) a[i] = p[i] * q[i];
+    fm_row_join(a);
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const f2 a_swapped = (f2){ AMPS_PI_2_F, AMPS_PI_2_F } - a[i];
+        a[i].x = sw[i][0] ? a_swapped.x : a[i].x;
+        a[i].y = sw[i][1] ? a_swapped.y : a[i].y;
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const f2 a_reflect = (f2){ AMPS_PI_F, AMPS_PI_F } - a[i];
+        a[i].x = re[i].x < 0.0f ? a_reflect.x : a[i].x;
+        a[i].y = re[i].y < 0.0f ? a_reflect.y : a[i].y;
+        out[i] = (f2){ __builtin_copysignf(a[i].x, im[i].x), __builtin_copysignf(a[i].y, im[i].y) };
+    }
+}
 // ta, tb = the two conj-products as (re, im) pairs
 __device__ __forceinline__ f2 fm_phase_core(f2 ta, f2 tb)
 {

@@ -1,5 +1,5 @@
 """Per-role phase timeline of chz12_kernel (a -DCHZ_TIMELINE build of the library): mean s_memtime cycles between the phase
-boundaries of workgroup 0's twelve waves.  usage (GPU box): AMPS_RECC_LIB=scripts/variants/tl.so [CHZ_ORDER=1] python scripts/chz_timeline.py [spec]"""
+boundaries of workgroup 0's twelve waves.  usage (GPU box): AMPS_RECC_LIB=scripts/variants/tl.so python scripts/chz_timeline.py [spec]"""
 import os
 import sys
 import numpy as np
@@ -18,11 +18,10 @@ for _ in range(6):
     r.push_wideband(x)
     r.drain()
 tl = np.fromfile("/tmp/chz_tl.bin", dtype=np.uint64).reshape(12, 8).astype(np.float64)
-order = int(os.environ.get("CHZ_ORDER", "1"))
 names = {0: "fold", 1: "pass2", 2: "p3+slicer"}
 print("spec %s, tag %s" % (spec, os.environ.get("AMPS_RECC_LIB", "").split("/")[-1]))
 for w in range(12):
-    role = (w >> 2) if order == 0 else 2 - (w >> 2)
+    role = 2 - (w >> 2)
     n = max(tl[w, 5], 1.0)
     a = tl[w, :5] / n        # a[k] = mean cycles from the previous stamp to stamp k
     tot = a.sum()

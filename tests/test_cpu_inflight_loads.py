@@ -63,7 +63,8 @@ def scan(asm_text):
             if len(nxt) >= 2:
                 segs = [range(k + 1, nxt[1])]
             else:       # the last two half-steps of the unrolled period: on to the loop's end, then from its head to the covering wait
-                tail_end = min(len(lines), loop[-1] + (loop[1] - loop[0]))
+                bar = next(q for q in range(loop[-1], len(lines)) if "s_barrier" in lines[q])    # the last half-step ends at its barrier
+                tail_end = min(len(lines), bar + 12)                                              # (+ the loop's back branch)
                 segs = [range(k + 1, tail_end), range(max(0, loop[0] - 30), loop[1 - len(nxt)])]
             for seg in segs:
                 hit = _touched(lines, seg, dst)
@@ -77,7 +78,7 @@ def scan(asm_text):
 
 def test_scanner_sees_a_planted_hazard():
     asm = "\n".join(["_ZN4amps12chz12_kernelXX:", "s_waitcnt vmcnt(8)", "global_load_dwordx2 v[10:11], v1, s[2:3]", "v_mov_b64_e32 v[20:21], v[10:11]",
-                     "s_waitcnt vmcnt(8)", "global_load_dwordx2 v[12:13], v1, s[2:3]", "s_waitcnt vmcnt(8)", "v_add_f32 v0, v10, v12", ".Lfunc_end0:"])
+                     "s_waitcnt vmcnt(8)", "global_load_dwordx2 v[12:13], v1, s[2:3]", "s_waitcnt vmcnt(8)", "v_add_f32 v0, v10, v12", "s_barrier", ".Lfunc_end0:"])
     res = scan(asm)
     assert len(res) == 1 and len(res[0][3]) >= 1 and "v_mov_b64" in res[0][3][0][3]
 
