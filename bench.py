@@ -35,6 +35,11 @@ ALG_BYTES_PER_SYMBOL_DIRECT = 80.0   # 8 B/sample x 10 samples/sym
 HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec (6290 GB/s measured copy ceiling)
 FP32_PEAK_TFLOPS = 157.3             # MI355X_MICROARCH.md: peak FP32 vector rate (packed)
 SLICERS = {"atan": "A", "product": "B", "sine": "C"}
+# C/N (30 kHz channel) at 1 % seizure-burst loss, scripts/slicer_sensitivity.py on one MI355X (profiles/r03/slicer_sensitivity.txt)
+SLICER_SENSITIVITY = {"unit": "dB C/N in 30 kHz at 1 % burst loss", "source": "profiles/r03/slicer_sensitivity.txt (1000 / 1248 bursts per point)",
+                      "wideband_seam": {"A": 9.6, "B": 11.7, "C": 13.3, "restated_reference_chain": 24.1},
+                      "iq_seam_behind_the_flow_graphs_channel_filter": {"A": 10.2, "B": 10.1, "C": 11.2, "restated_reference_chain": 24.8},
+                      "penalty_vs_A_wideband_dB": {"B": 2.0, "C": 3.7}}
 
 
 def parse(argv=None):
@@ -47,9 +52,10 @@ def parse(argv=None):
                     help="wideband832 = BASELINE configs[3] (headline): full band through the channelizer; direct832/direct1 = configs[1] style")
     ap.add_argument("--secondary", default="direct832", choices=["none", "direct832", "direct1", "wideband832"],
                     help="a second workload reported under 'secondary' (N=1 only)")
-    ap.add_argument("--slicer", default="sine", choices=list(SLICERS),
-                    help="numeric spec of the slicer (include/amps_recc_numerics.h): atan = spec A (discriminator + boxcar, the library default), "
-                         "sine = spec C (the same without the arctangent), product = spec B.  The other specs' kernel times are reported under 'other_slicer_specs'")
+    ap.add_argument("--slicer", default="default", choices=["default"] + list(SLICERS),
+                    help="numeric spec of the slicer (include/amps_recc_numerics.h).  default = whatever a handle created with no slicer flag "
+                         "uses (amps_recc_default_slicer(): spec A, arctangent discriminator + boxcar) -- the headline is the product's default path; "
+                         "sine = spec C (the same without the arctangent), product = spec B: opt-in variants, their kernel times are reported under 'other_slicer_specs'")
     ap.add_argument("--dist", default="bands", choices=["bands", "broadcast", "scatter_allgather"])
     ap.add_argument("--samples", type=int, default=0, help="per-channel samples per step (0 = workload default)")
     ap.add_argument("--taps", type=int, default=8, choices=[8], help="wideband832: prototype taps per polyphase branch")
@@ -496,7 +502,14 @@ def main(argv=None):
     if a.dist != "bands" and a.workload != "wideband832":
         raise SystemExit("--dist %s distributes a wideband block: use --workload wideband832" % a.dist)
 
+    from gr_amps_amd import capi
+    lib_default = capi.SLICER_NAMES[capi.load().amps_recc_default_slicer()]
+    is_default = a.slicer in ("default", lib_default)
+    if a.slicer == "default":
+        a.slicer = lib_default
     res, iq_base = run_workload(a.workload, a, torch, dev, dist, rank, world, local, a.slicer, a.steps, a.warmup)
+    res["config"]["slicer_is_library_default"] = is_default
+    res["config"]["slicer_sensitivity"] = SLICER_SENSITIVITY
     out = {
         "metric": "AMPS RECC Manchester symbols demodulated+decoded per second (real-time channels = value/0.02); achieved HBM GB/s vs peak",
         "value": res["value"], "unit": "Msym/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

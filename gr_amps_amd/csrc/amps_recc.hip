@@ -263,17 +263,21 @@ bool bits_kernel_is_front()   // AMPS_RECC_BITS_KERNEL=front: search the bit rin
     return v == 1;
 }
 
-int front_depth()   // tiles in flight per wave; AMPS_RECC_DEPTH overrides for experiments
+// tiles in flight per wave beyond the one being processed; AMPS_RECC_DEPTH overrides for experiments.  Measured with the
+// non-temporal tile loads (832 x 2^18, ms): spec A 0.329 at depth 1 / 0.342 at depth 2 (its discriminator needs the registers:
+// depth 2 costs a wave per SIMD); specs B / C 0.298 / 0.286: with the arctangent gone the kernel only waits for HBM
+int front_depth(int slicer)
 {
-    static int v = 0;
-    if (!v) { const char *e = std::getenv("AMPS_RECC_DEPTH"); v = e ? std::atoi(e) : 1; if (v < 1 || v > 3) v = 1; }   // measured: 1 -> 0.347 ms, 2 -> 0.370, 3 -> 0.452 (832 ch x 2^18)
-    return v;
+    static int env = -1;
+    if (env < 0) { const char *e = std::getenv("AMPS_RECC_DEPTH"); env = e ? std::atoi(e) : 0; if (env < 0 || env > 3) env = 0; }
+    if (env) return env;
+    return slicer == AMPS_SLICER_ATAN_BOXCAR ? 1 : 2;
 }
 template <int SPS> int front_blocks_per_cu(int slicer, bool tol)   // of the kernel launch_front<SPS> will pick
 {
     int n = 0;
     hipError_t e;
-    const int depth = front_depth();
+    const int depth = front_depth(slicer);
     if (slicer == AMPS_SLICER_PRODUCT) {
         if (tol) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, recc_front_kernel<SPS, 1, false, true, AMPS_SLICER_PRODUCT>, 256, 0);
         else if (depth == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, recc_front_kernel<SPS, 2, false, false, AMPS_SLICER_PRODUCT>, 256, 0);
@@ -307,18 +311,18 @@ template <int SPS> void launch_front(const FrontArgs &fa, dim3 grid, hipStream_t
 {
     if (slicer == AMPS_SLICER_PRODUCT) {
         if (fa.tol) hipLaunchKernelGGL((recc_front_kernel<SPS, 1, false, true, AMPS_SLICER_PRODUCT>), grid, dim3(256), 0, s, fa);
-        else if (front_depth() == 2) hipLaunchKernelGGL((recc_front_kernel<SPS, 2, false, false, AMPS_SLICER_PRODUCT>), grid, dim3(256), 0, s, fa);
+        else if (front_depth(slicer) == 2) hipLaunchKernelGGL((recc_front_kernel<SPS, 2, false, false, AMPS_SLICER_PRODUCT>), grid, dim3(256), 0, s, fa);
         else hipLaunchKernelGGL((recc_front_kernel<SPS, 1, false, false, AMPS_SLICER_PRODUCT>), grid, dim3(256), 0, s, fa);
         return;
     }
     if (slicer == AMPS_SLICER_SINE) {
         if (fa.tol) hipLaunchKernelGGL((recc_front_kernel<SPS, 1, false, true, AMPS_SLICER_SINE>), grid, dim3(256), 0, s, fa);
-        else if (front_depth() == 2) hipLaunchKernelGGL((recc_front_kernel<SPS, 2, false, false, AMPS_SLICER_SINE>), grid, dim3(256), 0, s, fa);
+        else if (front_depth(slicer) == 2) hipLaunchKernelGGL((recc_front_kernel<SPS, 2, false, false, AMPS_SLICER_SINE>), grid, dim3(256), 0, s, fa);
         else hipLaunchKernelGGL((recc_front_kernel<SPS, 1, false, false, AMPS_SLICER_SINE>), grid, dim3(256), 0, s, fa);
         return;
     }
     if (fa.tol) { hipLaunchKernelGGL((recc_front_kernel<SPS, 1, false, true>), grid, dim3(256), 0, s, fa); return; }
-    switch (front_depth()) {
+    switch (front_depth(slicer)) {
     case 3: hipLaunchKernelGGL((recc_front_kernel<SPS, 3>), grid, dim3(256), 0, s, fa); break;
     case 2: hipLaunchKernelGGL((recc_front_kernel<SPS, 2>), grid, dim3(256), 0, s, fa); break;
     default: hipLaunchKernelGGL((recc_front_kernel<SPS, 1>), grid, dim3(256), 0, s, fa); break;

@@ -383,6 +383,7 @@ __device__ __forceinline__ void chz_load1_ring(cf2 (&ring)[4][P + 4], const ChzI
         // register -- with "=v" the compiler is free to load into a scratch pair and copy it into place at the next control-flow
         // join, i.e. to READ a register whose load is still in flight (it did: tests/test_cpu_inflight_loads.py scans the
         // assembly for any access to such a register before the wait that covers it)
+        // (non-temporal loads change nothing here, 0.380 against 0.381 ms: the kernel is bound by VALU issue, not by its input stream)
         asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(ring[J][E]) : "v"(voff), "s"(q));
         asm volatile("global_load_dwordx2 %0, %1, %2 offset:2048" : "+v"(ring[J + 1][E]) : "v"(voff), "s"(q));
     } else {

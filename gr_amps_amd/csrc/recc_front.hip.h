@@ -41,6 +41,9 @@
 
 namespace amps {
 
+#ifndef AMPS_FRONT_NT
+#define AMPS_FRONT_NT 1                        // the tiles are read exactly once: non-temporal loads (measured 832 x 2^18: spec C 0.364 -> 0.327 ms, spec A 0.373 -> 0.349)
+#endif
 constexpr int TILE = AMPS_TILE_SAMPLES;      // 512 samples per wave tile
 constexpr int HALO = AMPS_HALO_SAMPLES;      // 1024 = 2 tiles of history per chunk / push
 constexpr int CARRY_CAP = HALO + 64;         // samples kept per channel between pushes
@@ -352,7 +355,11 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc
         if (s0 >= r_prev && s0 + TILE <= avail) {          // wave-uniform: entirely inside the new block
             const f4a8 *p = (const f4a8 *)(blk + (s0 - r_prev)) + lane;
 #pragma unroll
+#if AMPS_FRONT_NT
+            for (int q = 0; q < 4; q++) { f4a8 v = __builtin_nontemporal_load(p + 64 * q); r[q] = make_float4(v.x, v.y, v.z, v.w); }
+#else
             for (int q = 0; q < 4; q++) { f4a8 v = p[64 * q]; r[q] = make_float4(v.x, v.y, v.z, v.w); }
+#endif
         } else {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -448,12 +455,31 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc
         // ---- P1: prefetch the next tile, demodulate this one into LDS ----
         if (k + DEPTH < K) load_tile(nxt[DEPTH - 1], t0 + DEPTH * TILE);
         float *const dw = dcur + dw_off;
+        f2 dd4[4];
+        if constexpr (SL != AMPS_SLICER_SINE) {
+            // the four pairs of a tile are independent: their arctangents run in lock step (fm_phase_planar_n), not one serial
+            // Newton / Horner chain after the other
+            f2 re4[4], im4[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float ex = q == 0 ? last_x : lane63(cur[q - 1].z);
+                const float ey = q == 0 ? last_y : lane63(cur[q - 1].w);
+                const float pr = shift_in(cur[q].z, ex), pi_ = shift_in(cur[q].w, ey);
+                const f2 xa = { cur[q].x, cur[q].y }, xb = { cur[q].z, cur[q].w };
+                const f2 ta = conj_product(xa, (f2){ pr, pi_ }), tb = conj_product(xb, xa);
+                re4[q] = (f2){ ta.x, tb.x }; im4[q] = (f2){ ta.y, tb.y };
+            }
+            fm_phase_planar_n<4>(re4, im4, dd4);
+        }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const float ex = q == 0 ? last_x : lane63(cur[q - 1].z);
-            const float ey = q == 0 ? last_y : lane63(cur[q - 1].w);
-            const float pr = shift_in(cur[q].z, ex), pi_ = shift_in(cur[q].w, ey);
-            const f2 dd = SL == AMPS_SLICER_SINE ? sine_pair(cur[q], pr, pi_) : fm_phase_pair(cur[q], pr, pi_);
+            f2 dd;
+            if constexpr (SL == AMPS_SLICER_SINE) {
+                const float ex = q == 0 ? last_x : lane63(cur[q - 1].z);
+                const float ey = q == 0 ? last_y : lane63(cur[q - 1].w);
+                const float pr = shift_in(cur[q].z, ex), pi_ = shift_in(cur[q].w, ey);
+                dd = sine_pair(cur[q], pr, pi_);
+            } else dd = dd4[q];
             const float d0 = dd.x, d1 = dd.y;
             dw[didx(DHIST + 128 * q)] = d0;
             dw[didx(DHIST + 128 * q) + 1] = d1;

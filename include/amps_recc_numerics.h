@@ -64,6 +64,21 @@
  * weigh less, and the cost is 2 flops per sample instead of ~25.  Measured on the synthetic bursts
  * it decodes like spec A down to 8 dB SNR.  d' is not an FM-demod float in radians; the
  * stated-tolerance intermediate of spec A stays available through amps_recc_debug_demod.
+ *
+ * ---- which spec is the default, and what the others cost in sensitivity ----
+ * AMPS_SLICER_DEFAULT = spec A.  scripts/slicer_sensitivity.py (profiles/r03/slicer_sensitivity.txt; 1000 bursts per point on the
+ * IQ seam, 1248 on the wideband seam, C/N stated in a 30 kHz channel) gives the C/N at which 1 % of the seizure bursts are lost:
+ *
+ *                          spec A     spec B            spec C            restated reference chain (M&M timing)
+ *   IQ seam (behind the    10.2 dB    10.1 dB (-0.1)    11.2 dB (+1.0)    24.8 dB  (its loop must lock inside the four spare
+ *   flow graph's 299-tap                                                            dotting bits: 3 % of the bursts are lost
+ *   channel filter)                                                                 at 20 dB, 0.2 % at 30 dB)
+ *   wideband seam           9.6 dB    11.7 dB (+2.0)    13.3 dB (+3.7)    24.1 dB
+ *
+ * Undetected wrong words (flagged valid, different from what was sent) stay below 1e-3 of the valid words for every spec from
+ * 10 dB up.  Spec C saves 27 % of the filter-bank kernel's time and costs 3.7 dB on the wideband seam (three samples per symbol:
+ * the amplitude-weighted sine of a 0.84 rad step is a poorer statistic than the angle itself); spec B is free on band-limited
+ * input but wraps on white noise (8.1 dB -> 15.0 dB at 200 ksps without a channel filter).  Both stay opt-in.
  */
 #ifndef AMPS_RECC_NUMERICS_H
 #define AMPS_RECC_NUMERICS_H

@@ -1,15 +1,17 @@
 """Sensitivity of the three slicer specs (A atan + boxcar, B product detector, C sine discriminator) against the restated
-reference chain, burst-loss and wrong-word rate over SNR, on both seams.
+reference chain: burst-loss and wrong-word rate over the carrier-to-noise ratio, on both seams.
+C/N is stated in a 30 kHz AMPS channel bandwidth on both seams.
 
-  IQ seam   : one burst per channel-block of 40 000 samples at 200 ksps (10 samples per symbol), AWGN, SNR in the 200 kHz
-              sample bandwidth.  GPU: amps_recc_push_iq under specs A / B / C.  Reference column: oracle.chain_iq200 =
-              quadrature_demod_cf -> clock_recovery_mm_ff -> binary_slicer_fb -> recc -> recc_decode on the same samples
-              (grc/recctest.grc:458, 846-874, 807), one call per burst.
-  wideband  : 0.45 s blocks at 30.72 Msps, one burst in every second channel (416 per block) at a random offset, AWGN with the
-              SNR stated in a channel's 60 kHz.  GPU: amps_recc_push_wideband under specs A / B / C.  Reference column: every
-              planted channel is cut out of the same block at 400 ksps with the channel at +160 kHz (ideal FFT-domain band
-              extraction, float64 -- what an N210 tuned 160 kHz below the channel would deliver) and pushed through
-              oracle.chain_iq400 = the flow graph from its 299-tap freq_xlating_fir_filter_ccc on (grc/recctest.grc:889-937).
+  IQ seam   : one burst per block, synthesised as the flow graph's source delivers it -- 400 ksps, the channel at +160 kHz, white
+              noise (grc/recctest.grc:591) -- and passed through the flow graph's own channel filter (oracle.freq_xlating_fir
+              with the 299 firdes.low_pass taps, decim 2: grc/recctest.grc:889-937, 115-155).  The resulting 200 ksps stream is
+              what BOTH sides get: amps_recc_push_iq under specs A / B / C on the GPU, and oracle.chain_iq200 = quadrature_demod_cf
+              -> clock_recovery_mm_ff -> binary_slicer_fb -> recc -> recc_decode (grc/recctest.grc:458, 846-874, 807).
+  wideband  : 0.45 s blocks at 30.72 Msps, one burst in every second channel (416 per block) at a random offset, white noise.
+              GPU: amps_recc_push_wideband under specs A / B / C.  Reference column: every planted channel is cut out of the same
+              block at 400 ksps with the channel at +160 kHz (ideal FFT-domain band extraction, float64 -- what an N210 tuned
+              160 kHz below the channel would deliver) and pushed through oracle.chain_iq400 = the flow graph from its 299-tap
+              freq_xlating_fir_filter_ccc on.
 
 A burst is GOOD when a record on its channel carries the transmitted MIN and every transmitted word valid and equal to what
 was sent; LOST otherwise.  WRONG WORDS = words flagged valid whose 36 bits differ from the transmitted ones (undetected errors),
@@ -26,7 +28,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 NB = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-SNRS = list(range(6, 17))
+SNRS = list(range(6, 19))
+SNRS_HIGH = [20, 24, 30]          # where the restated reference chain's loss floor shows (its M&M loop must lock within the 4 spare dotting bits)
 SPECS = ("atan", "product", "sine")
 N_IQ = 40000
 FS = 30.72e6
@@ -52,15 +55,25 @@ def _score_recs(recs, min10, sent):
     return good, nvalid, nwrong
 
 
+_TAPS = None
+
+
 def iq_job(args):
-    """synthesise one burst block and run the restated reference chain on it"""
+    """one burst as the flow graph's source delivers it (400 ksps, channel at +160 kHz), through the flow graph's channel filter;
+    the restated reference chain runs on the filtered 200 ksps stream the GPU seam gets as well"""
+    global _TAPS
     seed, snr = args
     from gr_amps_amd import synth
     import oracle
-    x, t = synth.make_channel_block(N_IQ, 1, seed=seed, snr_db=float(snr), first=2000)
+    if _TAPS is None:
+        _TAPS = oracle.firdes_low_pass(3.0, 400e3, 10e3, 4.5e3)
+    # C/N in 30 kHz -> SNR in the 400 kHz sample bandwidth
+    x, t = synth.make_channel_block(2 * N_IQ, 1, seed=seed, sps=20, snr_db=float(snr) - 10.0 * np.log10(400.0 / 30.0), first=4000)
+    x = (x * np.exp(2j * np.pi * 0.4 * np.arange(x.size))).astype(np.complex64)
+    y = oracle.freq_xlating_fir(x, _TAPS, 160e3, 400e3, 2)[:N_IQ].astype(np.complex64)
     off, kind, min10, esn, dialed, words = t[0]
-    recs = oracle.chain_iq200(x, channel=0)
-    return x, min10, [list(w) for w in words], _score_recs(recs, min10, words)
+    recs = oracle.chain_iq200(y, channel=0)
+    return y, min10, [list(w) for w in words], _score_recs(recs, min10, words)
 
 
 def ref400_job(args):
@@ -90,8 +103,8 @@ def main():
     table = {}
 
     # ---------------- IQ seam
-    print("seam snr_dB sent | loss A / B / C / ref | wrong-word rate A / B / C / ref (valid words)", flush=True)
-    for snr in SNRS:
+    print("seam C/N_dB(30kHz) sent | loss A / B / C / ref | wrong-word rate A / B / C / ref (valid words)", flush=True)
+    for snr in SNRS + SNRS_HIGH:
         res = pool.map(iq_job, [(910000 + 1000 * snr + i, snr) for i in range(NB)], chunksize=8)
         iq = np.stack([r[0] for r in res])
         truth = [(r[1], r[2]) for r in res]
@@ -117,14 +130,14 @@ def main():
     assert n % 384 == 0
     blen = 3456 * 1536
     nblk = max(1, (NB + 415) // 416)
-    for snr in SNRS:
+    for snr in SNRS + SNRS_HIGH:
         tot = {k: np.zeros(3, np.int64) for k in SPECS + ("ref",)}
         sent_total = 0
         for b in range(nblk):
             rng = np.random.default_rng(77000 + 100 * snr + b)
             g = torch.Generator(device=dev)
             g.manual_seed(5000 + 100 * snr + b)
-            sigma = 10.0 ** (-snr / 20.0) / np.sqrt(2.0) * np.sqrt(FS / 60e3)
+            sigma = 10.0 ** (-snr / 20.0) / np.sqrt(2.0) * np.sqrt(FS / 30e3)      # C/N in 30 kHz
             x = torch.view_as_complex(torch.randn(n, 2, device=dev, generator=g, dtype=torch.float32) * float(sigma))
             planted = {}
             for c in range(0, Cw, 2):
@@ -167,12 +180,13 @@ def main():
               + " / ".join("%.1e (%d)" % (tot[k][2] / max(1, tot[k][1]), tot[k][1]) for k in SPECS + ("ref",)), flush=True)
 
     # ---------------- SNR at 1 % burst loss and the penalties
-    print("\nSNR (dB) at 1 %% burst loss, log-linear interpolation between the 1 dB points:")
+    print("\nSNR (dB) at 1 % burst loss, log-linear interpolation between the measured points:")
+    allsnr = SNRS + SNRS_HIGH
     for seam in ("iq", "wide"):
         cr = {}
         for k in SPECS + ("ref",):
-            loss = [1 - table[(seam, s)][k][0] / (NB if seam == "iq" else table[("wide_sent", s)]) for s in SNRS]
-            cr[k] = crossing(SNRS, loss)
+            loss = [1 - table[(seam, s)][k][0] / (NB if seam == "iq" else table[("wide_sent", s)]) for s in allsnr]
+            cr[k] = crossing(allsnr, loss)
         fmt = lambda v: "n/a" if v is None else "%.2f" % v
         pen = lambda k: "n/a" if (cr[k] is None or cr["atan"] is None) else "%+.2f" % (cr[k] - cr["atan"])
         print("%-4s A %s | B %s | C %s | reference chain %s || penalty vs A: B %s dB, C %s dB, reference chain %s dB"

@@ -107,7 +107,10 @@ def test_raw400_words_equal_reference_cpu_chain(gpu):
                 assert rr[f] == g[f], f
         n_ref += len(ref)
         n_gpu += len(got)
-    assert n_ref >= 0.5 * n_gpu, (n_ref, n_gpu)
+    # The restated chain's Mueller & Mueller loop has to lock inside the four dotting bits the precursor has to spare: at 30 dB it
+    # decodes ~99.8 % of the bursts (scripts/slicer_sensitivity.py, 1000 bursts per point); every one of them was compared above.
+    print("reference chain decoded %d of the %d bursts the GPU path decoded" % (n_ref, n_gpu))
+    assert n_ref >= n_gpu - 1, (n_ref, n_gpu)
 
 
 def test_xlate_argument_errors(gpu):
