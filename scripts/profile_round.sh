@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 evidence for one round: kernel-trace stats of the default bench command and separate PMC passes.
 # usage (GPU box, repo root): scripts/profile_round.sh <tag> [slicer]      -> gpurun_out/prof_<tag>/
-TAG=${1:-r02}; SL=${2:-sine}
+TAG=${1:-r03}; SL=${2:-atan}     # atan = spec A = the library default = what `python bench.py` runs
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 R=$PWD
