@@ -544,7 +544,7 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
     // frame), so there pass 3 moves to the pass-2 waves (spec A 0.537 -> 0.517 ms, spec C 0.399 -> 0.414 if it moved too).
     constexpr bool P3_WITH_P2 = !IQ && SL == AMPS_SLICER_ATAN_BOXCAR;
     const int wf = wave & 3;                                            // frame of a half-batch this wave transforms (roles 1, 2)
-    if (role == 2) __builtin_amdgcn_s_setprio(2); else if (role == 1) __builtin_amdgcn_s_setprio(1);
+    if (role == 2) __builtin_amdgcn_s_setprio(2); else if (role == 1) __builtin_amdgcn_s_setprio(1);   // (six other priority triples measured: all within the run-to-run noise of this one)
     const int64_t f0 = (int64_t)blockIdx.x * a.frames_per_wg;   // multiple of 64
     if (f0 >= (int64_t)a.nframes) return;
     int64_t f1 = f0 + a.frames_per_wg; if (f1 > (int64_t)a.nframes) f1 = a.nframes;
