@@ -443,12 +443,12 @@ template <int SL> struct ChzSlicePair {
     f2 pr, pi;               // spec A / C: the bins one frame earlier
     f2 d1, d2;               // spec A / C: the last two discriminator outputs
     f2 h1r, h1i, h2r, h2i, h3r, h3i;   // spec B: the bins one, two and three frames earlier
-    uint32_t gw[2];          // spec A: slicer bits, newest at bit 31; specs B / C: SIGN bits, newest at bit 0
+    uint32_t gw[2];          // SIGN bits of the statistic, newest at bit 0 (the slicer bit is the inverted sign)
     __device__ __forceinline__ void reset()
     {
         const f2 z = { 0.f, 0.f };
         pr = pi = d1 = d2 = h1r = h1i = h2r = h2i = h3r = h3i = z;
-        gw[0] = gw[1] = SL == AMPS_SLICER_ATAN_BOXCAR ? ~0u : 0u;     // "ones before the stream" in either representation
+        gw[0] = gw[1] = 0u;                                           // "ones before the stream": sign bits clear
     }
     template <int PAR> __device__ __forceinline__ void step(f2 yr, f2 yi)   // PAR = parity of the absolute frame index
     {
@@ -468,13 +468,9 @@ template <int SL> struct ChzSlicePair {
             }
             // window [n-2, n]: n even -> (d[n-2] + d[n-1]) + d[n];  n odd -> d[n-2] + (d[n-1] + d[n])
             const f2 s = PAR == 0 ? (d2 + d1) + d : d2 + (d1 + d);
-            if constexpr (SL == AMPS_SLICER_SINE) {
-                gw[0] = __builtin_amdgcn_alignbit(gw[0], __float_as_uint(s.x), 31);
-                gw[1] = __builtin_amdgcn_alignbit(gw[1], __float_as_uint(s.y), 31);
-            } else {
-                gw[0] = __builtin_amdgcn_alignbit(s.x >= 0.0f ? 1u : 0u, gw[0], 1);
-                gw[1] = __builtin_amdgcn_alignbit(s.y >= 0.0f ? 1u : 0u, gw[1], 1);
-            }
+            const f2 sp = SL == AMPS_SLICER_SINE ? s : s + (f2){ 0.0f, 0.0f };   // spec A: g = (S >= 0), i.e. -0 counts as +0 (see step4)
+            gw[0] = __builtin_amdgcn_alignbit(gw[0], __float_as_uint(sp.x), 31);
+            gw[1] = __builtin_amdgcn_alignbit(gw[1], __float_as_uint(sp.y), 31);
             d2 = d1; d1 = d;
             pr = yr; pi = yi;
         }
@@ -495,8 +491,12 @@ template <int SL> struct ChzSlicePair {
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const f2 s = (g & 1) == 0 ? (d2 + d1) + d[g] : d2 + (d1 + d[g]);
-                gw[0] = __builtin_amdgcn_alignbit(s.x >= 0.0f ? 1u : 0u, gw[0], 1);
-                gw[1] = __builtin_amdgcn_alignbit(s.y >= 0.0f ? 1u : 0u, gw[1], 1);
+                // g = (S >= 0): S + (+0) turns the one negative-signed value that counts as >= 0, -0, into +0 (and leaves every
+                // other finite S alone), after which the bit is the inverted sign -- one packed add and two funnel shifts for
+                // the pair instead of two compares, two selects and two shifts
+                const f2 sp = s + (f2){ 0.0f, 0.0f };
+                gw[0] = __builtin_amdgcn_alignbit(gw[0], __float_as_uint(sp.x), 31);
+                gw[1] = __builtin_amdgcn_alignbit(gw[1], __float_as_uint(sp.y), 31);
                 d2 = d1; d1 = d[g];
             }
             pr = yr[3]; pi = yi[3];
@@ -505,7 +505,7 @@ template <int SL> struct ChzSlicePair {
             for (int g = 0; g < 4; g++) { if (g & 1) step<1>(yr[g], yi[g]); else step<0>(yr[g], yi[g]); }
         }
     }
-    __device__ __forceinline__ uint32_t word(int e) const { return SL == AMPS_SLICER_ATAN_BOXCAR ? gw[e] : ~__builtin_bitreverse32(gw[e]); }
+    __device__ __forceinline__ uint32_t word(int e) const { return ~__builtin_bitreverse32(gw[e]); }
 };
 
 // Timeline hook (builds with -DCHZ_TIMELINE only; scripts/chz_timeline.py): every wave of workgroup 0 accumulates, in registers,
