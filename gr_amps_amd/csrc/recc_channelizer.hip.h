@@ -508,6 +508,117 @@ template <int SL> struct ChzSlicePair {
     __device__ __forceinline__ uint32_t word(int e) const { return ~__builtin_bitreverse32(gw[e]); }
 };
 
+// The slicer of a role: NP channel pairs per lane, pairs J0 .. J0 + NP - 1.
+// Bin ownership: pair j of (wave w, lane l) holds bins 512 j + 128 w + l and + 64: one block of the planar layout, so the four
+// floats a frame brings for a pair sit at base + {0, 64, 128, 192} (two ds_read2st64_b32), consecutive lanes read consecutive
+// floats, and the register pairs are (re, re) and (im, im) of the two channels.  A pair-wave whose 128 bins are all outside the
+// active channels is skipped (none at 832 channels from bin 96: every block has active bins).
+template <int SL, bool IQ, int J0, int NP> struct ChzSlicer {
+    static constexpr int NB = CHZ_BATCH, M = CHZ_M;
+    ChzSlicePair<SL> S[NP];
+    uint32_t ch[NP][2];                                           // channel of the bin (>= n_channels: not an active channel)
+    bool pair_on[NP];
+    uint32_t hold[NP][2][4];                                      // finished ring words waiting for their 16-byte store
+    int nheld, pbase;
+    uint64_t mask32;
+    __device__ __forceinline__ void init(const ChzArgs &a, int wf, int lane)
+    {
+        pbase = 256 * wf + lane;                                  // chz_planar(128 wf + lane); pair j is 1024 floats further
+        nheld = 0;
+        mask32 = 2ull * a.ring_words - 1;
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+            S[j].reset();
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                ch[j][e] = ((uint32_t)(512 * (J0 + j) + 128 * wf + 64 * e + lane) - a.first_bin) & (M - 1);
+#pragma unroll
+                for (int k = 0; k < 4; k++) hold[j][e][k] = 0u;
+            }
+            pair_on[j] = __ballot(ch[j][0] < a.n_channels || ch[j][1] < a.n_channels) != 0;   // wave-uniform
+        }
+    }
+    // the four frames of half-batch hs: slice (or, unfused, store) this lane's bins
+    __device__ __forceinline__ void half(const ChzArgs &a, const cf2 *buf, int64_t fs, int64_t f0, int64_t f1, int hs)
+    {
+        const int64_t F = fs + (int64_t)NB * hs;          // first frame of the half-batch (multiple of 4)
+        const float *Af = (const float *)(buf + (hs & (CHZ_SLOTS - 1)) * NB * CHZ_FB);
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+            if (!pair_on[j]) continue;
+            f2 yr[NB], yi[NB];
+#pragma unroll
+            for (int g = 0; g < NB; g++) {
+                const float *q = Af + pbase + g * CHZ_FBF + 1024 * (J0 + j);
+                yr[g] = (f2){ q[0], q[64] };
+                yi[g] = (f2){ q[128], q[192] };
+            }
+            if constexpr (IQ) {
+                // four frames of a bin leave as one 32-byte run of the channel-major block
+                const int ng = (int)(f1 - F < (int64_t)NB ? f1 - F : (int64_t)NB);
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    if (ch[j][e] < a.n_channels) {
+                        float2 *dstp = a.out + (uint64_t)ch[j][e] * a.ld + F;
+                        if (ng == NB) {
+#pragma unroll
+                            for (int g = 0; g < NB; g += 2)
+                                *(float4 *)(dstp + g) = make_float4(yr[g][e], yi[g][e], yr[g + 1][e], yi[g + 1][e]);
+                        } else {
+#pragma unroll
+                            for (int g = 0; g < NB; g++)
+                                if (g < ng) dstp[g] = make_float2(yr[g][e], yi[g][e]);
+                        }
+                    }
+                }
+            } else {
+                S[j].step4(yr, yi);
+            }
+        }
+        if constexpr (!IQ) {
+            if (a.stream_start && F < 0) {                // frames before the stream are exactly +0 (the FFT of zeros may hold -0):
+                asm volatile("" ::: "memory");            // the state they leave is that of a fresh stream (a real branch, twice per launch)
+                S[0].reset(); S[1].reset();
+            }
+            if (F >= f0 && ((F + NB - 1) & 31) == 31) {   // 32 real frames collected (f0 is a multiple of 64)
+                // A channel's words leave as ONE 16-byte store per 128 frames (aligned group of four ring dwords): single
+                // dwords scattered over the channels' ring rows are counted -- and written -- as 32-byte sectors, 8x the 27 MB
+                // of slicer bits per GiB of input (round 1: 215 MB of 1.36 GB traffic).  Ranges start and end on 64-frame
+                // boundaries, so a run that is not a whole group is exactly two words.
+                const uint64_t w = (a.n_done + (uint64_t)(F + NB - 1)) >> 5;   // absolute ring dword of the finished word
+                const bool last = F + NB >= f1;
+#pragma unroll
+                for (int j = 0; j < NP; j++)
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        uint32_t word = S[j].word(e);
+                        if (SL == AMPS_SLICER_PRODUCT && a.stream_start && F + NB - 1 == 31) word |= 7u;   // no partner yet: g = 1
+                        hold[j][e][0] = hold[j][e][1]; hold[j][e][1] = hold[j][e][2]; hold[j][e][2] = hold[j][e][3]; hold[j][e][3] = word;
+                    }
+                nheld++;
+                if ((w & 3) == 3 || last) {
+#pragma unroll
+                    for (int j = 0; j < NP; j++)
+#pragma unroll
+                        for (int e = 0; e < 2; e++) {
+                            if (ch[j][e] < a.n_channels) {
+                                uint32_t *row = (uint32_t *)(a.gring + (uint64_t)ch[j][e] * a.ring_words);
+                                if (nheld == 4 && (w & 3) == 3) *(uint4 *)(row + ((w - 3) & mask32)) = make_uint4(hold[j][e][0], hold[j][e][1], hold[j][e][2], hold[j][e][3]);
+                                else if (nheld == 2) *(uint2 *)(row + ((w - 1) & mask32)) = make_uint2(hold[j][e][2], hold[j][e][3]);
+                                else {                                             // not reached (ranges are multiples of 64 frames); constant register indices
+#pragma unroll
+                                    for (int k = 0; k < 4; k++)
+                                        if (k >= 4 - nheld) row[(w - (uint64_t)(3 - k)) & mask32] = hold[j][e][k];
+                                }
+                            }
+                        }
+                    nheld = 0;
+                }
+            }
+        }
+    }
+};
+
 // Timeline hook (builds with -DCHZ_TIMELINE only; scripts/chz_timeline.py): every wave of workgroup 0 accumulates, in registers,
 // the s_memtime spent between its phase boundaries over the time steps >= CHZ_TL_FIRST and writes the sums once, at the end
 // (no memory traffic inside the loop: stores would count in the fold role's vmcnt window and stall it)
@@ -542,7 +653,7 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
     // Which role runs pass 3.  Behind the cheap slicers (specs B, C: 7 instructions per channel pair and frame) it shares the
     // slicer's waves; spec A's arctangent makes the slicer the longest chain of a time step (46 instructions per pair and
     // frame), so there pass 3 moves to the pass-2 waves (spec A 0.537 -> 0.517 ms, spec C 0.399 -> 0.414 if it moved too).
-    constexpr bool P3_WITH_P2 = !IQ && SL == AMPS_SLICER_ATAN_BOXCAR;
+    constexpr bool P3_WITH_P2 = !IQ && SL == AMPS_SLICER_ATAN_BOXCAR;   // (handing one of the slicer's two channel pairs to the pass-2 role instead: 0.518 against 0.494)
     const int wf = wave & 3;                                            // frame of a half-batch this wave transforms (roles 1, 2)
     if (role == 2) __builtin_amdgcn_s_setprio(2); else if (role == 1) __builtin_amdgcn_s_setprio(1);   // (six other priority triples measured: all within the run-to-run noise of this one)
     const int64_t f0 = (int64_t)blockIdx.x * a.frames_per_wg;   // multiple of 64
@@ -676,103 +787,14 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
 #pragma unroll
             for (int r = 1; r < 16; r++) tw3[r - 1] = chz_twiddle(r * lane, 1024);
         }
-        // Bin ownership: pair j of (wave w, lane l) holds bins 512 j + 128 w + l and + 64: one block of the planar layout, so the
-        // four floats a frame brings for a pair sit at base + {0, 64, 128, 192} (two ds_read2st64_b32), consecutive lanes read
-        // consecutive floats, and the register pairs are (re, re) and (im, im) of the two channels.  A pair-wave whose 128
-        // bins are all outside the active channels is skipped (none at 832 channels from bin 96: every block has active bins).
-        ChzSlicePair<SL> S[2];
-        uint32_t ch[2][2];                                        // channel of the bin (>= n_channels: not an active channel)
-        bool pair_on[2];
-        const int pbase = 256 * wf + lane;                        // chz_planar(128 wf + lane); pair j is 1024 floats further
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            S[j].reset();
-#pragma unroll
-            for (int e = 0; e < 2; e++) ch[j][e] = ((uint32_t)(512 * j + 128 * wf + 64 * e + lane) - a.first_bin) & (M - 1);
-            pair_on[j] = __ballot(ch[j][0] < a.n_channels || ch[j][1] < a.n_channels) != 0;   // wave-uniform
-        }
-        uint32_t hold[2][2][4] = {};                              // finished ring words of the four channels waiting for their 16-byte store
-        int nheld = 0;
-        const uint64_t mask32 = 2ull * a.ring_words - 1;
-        auto slice_half = [&](int hs) {                           // the four frames of half-batch hs: slice (or, unfused, store) this lane's bins
-            const int64_t F = fs + (int64_t)NB * hs;          // first frame of the half-batch (multiple of 4)
-            const float *Af = (const float *)(buf + (hs & (CHZ_SLOTS - 1)) * NB * CHZ_FB);
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                if (!pair_on[j]) continue;
-                f2 yr[NB], yi[NB];
-#pragma unroll
-                for (int g = 0; g < NB; g++) {
-                    const float *q = Af + pbase + g * CHZ_FBF + 1024 * j;
-                    yr[g] = (f2){ q[0], q[64] };
-                    yi[g] = (f2){ q[128], q[192] };
-                }
-                if constexpr (IQ) {
-                    // four frames of a bin leave as one 32-byte run of the channel-major block
-                    const int ng = (int)(f1 - F < (int64_t)NB ? f1 - F : (int64_t)NB);
-#pragma unroll
-                    for (int e = 0; e < 2; e++) {
-                        if (ch[j][e] < a.n_channels) {
-                            float2 *dstp = a.out + (uint64_t)ch[j][e] * a.ld + F;
-                            if (ng == NB) {
-#pragma unroll
-                                for (int g = 0; g < NB; g += 2)
-                                    *(float4 *)(dstp + g) = make_float4(yr[g][e], yi[g][e], yr[g + 1][e], yi[g + 1][e]);
-                            } else {
-#pragma unroll
-                                for (int g = 0; g < NB; g++)
-                                    if (g < ng) dstp[g] = make_float2(yr[g][e], yi[g][e]);
-                            }
-                        }
-                    }
-                } else {
-                    S[j].step4(yr, yi);
-                }
-            }
-            if constexpr (!IQ) {
-                if (a.stream_start && F < 0) {                // frames before the stream are exactly +0 (the FFT of zeros may hold -0):
-                    asm volatile("" ::: "memory");            // the state they leave is that of a fresh stream (a real branch, twice per launch)
-                    S[0].reset(); S[1].reset();
-                }
-                if (F >= f0 && ((F + NB - 1) & 31) == 31) {   // 32 real frames collected (f0 is a multiple of 64)
-                    // A channel's words leave as ONE 16-byte store per 128 frames (aligned group of four ring dwords): single
-                    // dwords scattered over the channels' ring rows are counted -- and written -- as 32-byte sectors, 8x the 27 MB
-                    // of slicer bits per GiB of input (round 1: 215 MB of 1.36 GB traffic).  Ranges start and end on 64-frame
-                    // boundaries, so a run that is not a whole group is exactly two words.
-                    const uint64_t w = (a.n_done + (uint64_t)(F + NB - 1)) >> 5;   // absolute ring dword of the finished word
-                    const bool last = F + NB >= f1;
-#pragma unroll
-                    for (int j = 0; j < 2; j++)
-#pragma unroll
-                        for (int e = 0; e < 2; e++) {
-                            uint32_t word = S[j].word(e);
-                            if (SL == AMPS_SLICER_PRODUCT && a.stream_start && F + NB - 1 == 31) word |= 7u;   // no partner yet: g = 1
-                            hold[j][e][0] = hold[j][e][1]; hold[j][e][1] = hold[j][e][2]; hold[j][e][2] = hold[j][e][3]; hold[j][e][3] = word;
-                        }
-                    nheld++;
-                    if ((w & 3) == 3 || last) {
-#pragma unroll
-                        for (int j = 0; j < 2; j++)
-#pragma unroll
-                            for (int e = 0; e < 2; e++) {
-                                if (ch[j][e] < a.n_channels) {
-                                    uint32_t *row = (uint32_t *)(a.gring + (uint64_t)ch[j][e] * a.ring_words);
-                                    if (nheld == 4 && (w & 3) == 3) *(uint4 *)(row + ((w - 3) & mask32)) = make_uint4(hold[j][e][0], hold[j][e][1], hold[j][e][2], hold[j][e][3]);
-                                    else if (nheld == 2) *(uint2 *)(row + ((w - 1) & mask32)) = make_uint2(hold[j][e][2], hold[j][e][3]);
-                                    else for (int k = 0; k < nheld; k++) row[(w - (uint64_t)(nheld - 1 - k)) & mask32] = hold[j][e][4 - nheld + k];   // not reached: ranges are multiples of 64 frames
-                                }
-                            }
-                        nheld = 0;
-                    }
-                }
-            }
-        };
+        ChzSlicer<SL, IQ, 0, 2> slicer;
+        slicer.init(a, wf, lane);
         __syncthreads();                                          // all roles start together 
         {
             for (int i = 0; i < nh + 3; i++) {
                 const int hs = i - 3, h3 = i - 2;
                 CHZ_STAMP(i, 0);
-                if (hs >= 0 && hs < nh) slice_half(hs);
+                if (hs >= 0 && hs < nh) slicer.half(a, buf, fs, f0, f1, hs);
                 CHZ_STAMP(i, 1);
                 if constexpr (!P3_WITH_P2) { if (h3 >= 0 && h3 < nh) chz_p3(buf + ((h3 & (CHZ_SLOTS - 1)) * NB + wf) * CHZ_FB, tw3, lane); }
                 CHZ_STAMP(i, 3);
