@@ -57,6 +57,9 @@ def parse(argv=None):
                          "uses (amps_recc_default_slicer(): spec A, arctangent discriminator + boxcar) -- the headline is the product's default path; "
                          "sine = spec C (the same without the arctangent), product = spec B: opt-in variants, their kernel times are reported under 'other_slicer_specs'")
     ap.add_argument("--dist", default="bands", choices=["bands", "broadcast", "scatter_allgather"])
+    ap.add_argument("--groups", type=int, default=0, choices=[0, 2, 4, 8],
+                    help="N = 1 only: run wideband832 as ONE rank of the one-band split over that many GPUs (cfg.wideband_groups: the rank decodes one "
+                         "interleaved channel group and skips the last FFT pass and the slicer for the others' bins) -- the per-rank kernel time of --dist broadcast")
     ap.add_argument("--samples", type=int, default=0, help="per-channel samples per step (0 = workload default)")
     ap.add_argument("--taps", type=int, default=8, choices=[8], help="wideband832: prototype taps per polyphase branch")
     ap.add_argument("--prewarm-ms", type=float, default=400.0, help="untimed clock-settling run of the same step before the warmup steps")
@@ -301,19 +304,32 @@ def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, w
         sps, C, first_bin = 3, 832, 96
         NW = a.samples or (1 << 27)                       # wideband samples per step (1 GiB, 4.4 s of signal)
         N = NW // 512                                     # samples per channel after the channelizer
-        if one_band:                                      # rank r decodes channel group r of rank 0's band
+        wb = {"channels": 1024, "decim": 512, "taps_per_branch": a.taps, "first_channel": first_bin}
+        n_band = C
+        groups, group = (world, rank) if one_band else ((a.groups, a.groups - 1) if (a.groups and dist is None) else (0, 0))
+        if groups in (2, 4, 8):
+            # one band, interleaved channel groups (cfg.wideband_groups): rank r decodes the channels whose FFT bin k has (k mod 64)
+            # in its window, and its filter-bank kernel skips pass 3 and the slicer for everybody else's bins
+            mine = [c for c in range(832) if (((96 + c) % 1024) % 64) // (64 // groups) == group]
+            wb.update(groups=groups, group=group)
+            batch, planted = make_wideband_batch(torch, dev, NW, 96, 832, 2, seed=1)     # the same block everywhere (only rank 0's is used)
+            planted = {c: m for c, m in planted.items() if c in set(mine)}
+            C = len(mine)
+        elif one_band:                                    # world sizes without a group split: contiguous channel ranges, whole filter bank per rank
             C = 832 // world
             first_bin = 96 + rank * C
-            batch, planted = make_wideband_batch(torch, dev, NW, 96, 832, 2, seed=1)     # the same block everywhere (only rank 0's is used)
+            wb["first_channel"] = first_bin
+            n_band = C
+            batch, planted = make_wideband_batch(torch, dev, NW, 96, 832, 2, seed=1)
             planted = {c - rank * C: m for c, m in planted.items() if rank * C <= c < (rank + 1) * C}
-            recv = [torch.empty_like(batch), torch.empty_like(batch)]
         else:
             batch, planted = make_wideband_batch(torch, dev, NW, first_bin, C, 2, seed=rank + 1)
+        if one_band:
+            recv = [torch.empty_like(batch), torch.empty_like(batch)]
         expected = len(planted)
         iq_base = None
-        r = capi.Recc(n_channels=C, sps=sps, max_samples=N + 8, max_bursts=max(4096, 2 * expected), device=local, time_kernels=True,
-                      slicer=slicer, sync_torch=False,
-                      wideband={"channels": 1024, "decim": 512, "taps_per_branch": a.taps, "first_channel": first_bin})
+        r = capi.Recc(n_channels=n_band, sps=sps, max_samples=N + 8, max_bursts=max(4096, 2 * expected), device=local, time_kernels=True,
+                      slicer=slicer, sync_torch=False, wideband=wb)
         step_no = [0]
         busy = [None, None]                               # per receive buffer: event behind the kernels that last read it
 
@@ -419,7 +435,8 @@ def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, w
     del batch
     torch.cuda.empty_cache()
     syms_per_step_rank = C * (NW / 1536.0) if wide else C * N / sps
-    value = syms_per_step_rank * steps * world / el      # one-band modes: the ranks' channel groups add up to the band
+    # whole-job symbols: every rank its own band (bands), or the ONE band the ranks split between them (one-band modes)
+    value = (832 * (NW / 1536.0) if one_band else syms_per_step_rank * world) * steps / el
     if wide:   # dominant kernel = the channelizer; algorithmic bytes = the wideband block read once (14.77 B/symbol at 832 channels)
         kms = tm["ms_channelizer"] / max(1, tm["launches_channelizer"])
         alg_bytes = 8.0 * NW
@@ -440,9 +457,16 @@ def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, w
     tfl = flops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
     drain_note = "" if a.no_pipeline else " (split drain: collected while the next step runs)"
     prof = profile_traffic(name + ":" + slicer)
-    par = ("%s: rank 0's block by RCCL %s every step, rank r decodes channels [%d r, %d (r+1)); the filter bank runs on every rank"
-           % (a.dist, "broadcast" if a.dist == "broadcast" else "scatter + all-gather", C, C)) if one_band else \
-          "bands sharded x%d (one 832-channel band per GPU), no data-path collective" % world
+    if wide and groups in (2, 4, 8):
+        par = ("one band, %d interleaved channel groups (cfg.wideband_groups), this line = group %d: %d channels; every rank folds the whole stream, "
+               "pass 3 of the FFT and the slicer run for the rank's own bins only%s"
+               % (groups, group, C, ("; rank 0's block by RCCL %s every step" % ("broadcast" if a.dist == "broadcast" else "scatter + all-gather")) if one_band else
+                  " (single-GPU measurement of one rank's share, --groups)"))
+    elif one_band:
+        par = ("%s: rank 0's block by RCCL %s every step, rank r decodes channels [%d r, %d (r+1)); the whole filter bank runs on every rank"
+               % (a.dist, "broadcast" if a.dist == "broadcast" else "scatter + all-gather", C, C))
+    else:
+        par = "bands sharded x%d (one 832-channel band per GPU), no data-path collective" % world
     res = {
         "value": round(value / 1e6, 3), "ms_per_step": round(el / steps * 1e3, 4),
         "config": {"workload": ("wideband832 (BASELINE configs[3]): one fc32 stream @30.72 Msps, %d samples per step per GPU -> 1024-branch "

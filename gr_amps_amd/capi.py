@@ -53,7 +53,7 @@ class Cfg(C.Structure):
         ("max_samples_per_push", C.c_uint32), ("max_bursts", C.c_uint32), ("device", C.c_int32),
         ("flags", C.c_uint32), ("wideband_channels", C.c_uint32), ("wideband_decim", C.c_uint32),
         ("wideband_taps_per_branch", C.c_uint32), ("wideband_first_channel", C.c_uint32),
-        ("sync_tolerance", C.c_uint32), ("stream", C.c_void_p),
+        ("sync_tolerance", C.c_uint32), ("wideband_groups", C.c_uint32), ("wideband_group", C.c_uint32), ("stream", C.c_void_p),
     ]
 
 
@@ -213,6 +213,8 @@ class Recc:
             cfg.wideband_decim = wideband["decim"]
             cfg.wideband_taps_per_branch = wideband.get("taps_per_branch", 8)
             cfg.wideband_first_channel = wideband.get("first_channel", 0)
+            cfg.wideband_groups = wideband.get("groups", 0)
+            cfg.wideband_group = wideband.get("group", 0)
         self.n_channels, self.sps, self.max_bursts, self.max_samples = n_channels, sps, max_bursts, max_samples
         self._h = C.c_void_p()
         rc = L.amps_recc_create(C.byref(self._h), C.byref(cfg))

@@ -497,6 +497,12 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
     h->cfg = *cfg;
     h->device = dev;
     h->C = cfg->n_channels;
+    if (cfg->wideband_channels && cfg->wideband_groups > 1) {      // a channel-group handle owns only its group's rows
+        if (cfg->flags & AMPS_RECC_FLAG_UNFUSED_WIDEBAND) { delete h; return -EINVAL; }
+        const int rows = chz_rows(*cfg, nullptr, nullptr);
+        if (rows < 1) { delete h; return -EINVAL; }
+        h->C = (uint32_t)rows;
+    }
     h->sps = cfg->samples_per_symbol;
     h->slicer = (cfg->flags & AMPS_RECC_FLAG_SLICER_PRODUCT) ? AMPS_SLICER_PRODUCT
               : (cfg->flags & AMPS_RECC_FLAG_SLICER_SINE) ? AMPS_SLICER_SINE
@@ -995,6 +1001,8 @@ static int drain_end_impl(amps_recc_t *h, amps_recc_burst_t *out, uint8_t *burst
         std::sort(keys.begin(), keys.end(), [](const Key &x, const Key &y) { return x.k < y.k; });
         size_t k = std::min<size_t>(n, cap);
         if (out) for (size_t i = 0; i < k; i++) std::memcpy(&out[i], &r[keys[i].i], sizeof(amps_recc_burst_t));
+        if (out && h->chz.enabled && h->chz.groups > 1)               // rows of a channel group -> channel numbers of the band selection
+            for (size_t i = 0; i < k; i++) out[i].channel = out[i].channel < h->chz.row2chan.size() ? h->chz.row2chan[out[i].channel] : out[i].channel;
         if (bursts_out && h->bsym_host_buf[b])
             for (size_t i = 0; i < k; i++)
                 std::memcpy(bursts_out + i * AMPS_RECC_CAPTURE_SYMS, h->bsym_host_buf[b] + (size_t)keys[i].i * AMPS_RECC_CAPTURE_SYMS, AMPS_RECC_CAPTURE_SYMS);

@@ -69,8 +69,11 @@ struct ChzArgs {
     uint32_t nsamp;          // new samples
     uint32_t nframes;        // frames produced by this launch
     uint32_t frames_per_wg;  // multiple of 64
-    uint32_t first_bin;      // FFT bin of channel 0
-    uint32_t n_channels;
+    uint32_t first_bin;      // FFT bin of channel 0 (host bookkeeping; the kernel goes by bin2row)
+    uint32_t n_channels;     // rows of `out` / `gring` this handle owns
+    const uint16_t *bin2row; // [M]: row of FFT bin k in `out` / `gring`, >= n_channels for a bin this handle does not decode
+    uint32_t grp_w, grp_r;   // channel groups (cfg.wideband_groups): this handle's bins are those with (k mod 64) in [grp_r * grp_w,
+                             // (grp_r + 1) * grp_w); grp_w = 64, grp_r = 0: every bin
     uint32_t odd_start;      // parity of (absolute frame index of frame 0 of this launch)
     uint32_t hist;           // samples of history the carry holds before v = 0  (L - D + CHZ_PRE * D)
     // fused form: slicer bits go straight to the RECC bit ring
@@ -509,29 +512,35 @@ template <int SL> struct ChzSlicePair {
 };
 
 // The slicer of a role: NP channel pairs per lane, pairs J0 .. J0 + NP - 1.
-// Bin ownership: pair j of (wave w, lane l) holds bins 512 j + 128 w + l and + 64: one block of the planar layout, so the four
-// floats a frame brings for a pair sit at base + {0, 64, 128, 192} (two ds_read2st64_b32), consecutive lanes read consecutive
-// floats, and the register pairs are (re, re) and (im, im) of the two channels.  A pair-wave whose 128 bins are all outside the
-// active channels is skipped (none at 832 channels from bin 96: every block has active bins).
+// Bin ownership.  The planar layout keeps a frame in eight blocks of 128 bins, [re of bins 0..63 | re of 64..127 | im | im]; a lane's
+// PAIR is two bins 64 apart in one block, so the four floats a frame brings for it sit at base + {0, 64, 128, 192} (two
+// ds_read2st64_b32) and arrive as the register pairs (re, re) and (im, im) of its two channels.  With W = grp_w residues per
+// block belonging to this handle (64 = all of them) a frame holds 8 W pairs, numbered vp = W * block + i'; pair j of (wave wf, lane)
+// is vp = 64 (4 (J0 + j) + wf) + lane.  W = 64: pair j holds bins 512 j + 128 wf + lane and + 64, consecutive lanes read consecutive
+// floats.  A pair-wave none of whose bins is decoded by this handle is skipped (wave-uniform).
 template <int SL, bool IQ, int J0, int NP> struct ChzSlicer {
     static constexpr int NB = CHZ_BATCH, M = CHZ_M;
     ChzSlicePair<SL> S[NP];
-    uint32_t ch[NP][2];                                           // channel of the bin (>= n_channels: not an active channel)
+    uint32_t ch[NP][2];                                           // row of the bin (>= n_channels: not decoded by this handle)
+    uint32_t pbase[NP];                                           // float offset of the pair's first real part in a planar frame
     bool pair_on[NP];
     uint32_t hold[NP][2][4];                                      // finished ring words waiting for their 16-byte store
-    int nheld, pbase;
+    int nheld;
     uint64_t mask32;
     __device__ __forceinline__ void init(const ChzArgs &a, int wf, int lane)
     {
-        pbase = 256 * wf + lane;                                  // chz_planar(128 wf + lane); pair j is 1024 floats further
         nheld = 0;
         mask32 = 2ull * a.ring_words - 1;
 #pragma unroll
         for (int j = 0; j < NP; j++) {
             S[j].reset();
+            const uint32_t vp = 64u * (4u * (J0 + j) + (uint32_t)wf) + (uint32_t)lane;
+            const bool valid = vp < 8u * a.grp_w;
+            const uint32_t blk = vp / a.grp_w, ip = vp - blk * a.grp_w, k0 = 128u * blk + a.grp_r * a.grp_w + ip;
+            pbase[j] = valid ? 256u * blk + a.grp_r * a.grp_w + ip : 0u;
 #pragma unroll
             for (int e = 0; e < 2; e++) {
-                ch[j][e] = ((uint32_t)(512 * (J0 + j) + 128 * wf + 64 * e + lane) - a.first_bin) & (M - 1);
+                ch[j][e] = valid ? (uint32_t)a.bin2row[(k0 + 64u * e) & (M - 1)] : 0xffffu;
 #pragma unroll
                 for (int k = 0; k < 4; k++) hold[j][e][k] = 0u;
             }
@@ -549,7 +558,7 @@ template <int SL, bool IQ, int J0, int NP> struct ChzSlicer {
             f2 yr[NB], yi[NB];
 #pragma unroll
             for (int g = 0; g < NB; g++) {
-                const float *q = Af + pbase + g * CHZ_FBF + 1024 * (J0 + j);
+                const float *q = Af + pbase[j] + g * CHZ_FBF;
                 yr[g] = (f2){ q[0], q[64] };
                 yi[g] = (f2){ q[128], q[192] };
             }
@@ -655,6 +664,12 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
     // frame), so there pass 3 moves to the pass-2 waves (spec A 0.537 -> 0.517 ms, spec C 0.399 -> 0.414 if it moved too).
     constexpr bool P3_WITH_P2 = !IQ && SL == AMPS_SLICER_ATAN_BOXCAR;   // (handing one of the slicer's two channel pairs to the pass-2 role instead: 0.518 against 0.494)
     const int wf = wave & 3;                                            // frame of a half-batch this wave transforms (roles 1, 2)
+    // Pass 3 produces the bins n = i (mod 64) from the points i + 64 r: a handle that decodes one channel group only needs the grp_w
+    // residues of its group, so the four frames of a half-batch pack into 4 grp_w lanes: virtual lane v = 64 wf + lane transforms
+    // residue i = grp_r grp_w + v % grp_w of frame v / grp_w (grp_w = 64: lane i of wave wf, frame wf, as ever)
+    const uint32_t p3_v = 64u * (uint32_t)wf + (uint32_t)lane;
+    const bool p3_on = p3_v < 4u * a.grp_w;
+    const int p3_f = (int)(p3_v / a.grp_w) & 3, p3_i = (int)(a.grp_r * a.grp_w + p3_v % a.grp_w);
     if (role == 2) __builtin_amdgcn_s_setprio(2); else if (role == 1) __builtin_amdgcn_s_setprio(1);   // (six other priority triples measured: all within the run-to-run noise of this one)
     const int64_t f0 = (int64_t)blockIdx.x * a.frames_per_wg;   // multiple of 64
     if (f0 >= (int64_t)a.nframes) return;
@@ -764,7 +779,7 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
         cf2 tw3[P3_WITH_P2 ? 15 : 1];                             // twiddles of the second radix-16 pass: W_1024^{r lane}
         if constexpr (P3_WITH_P2) {
 #pragma unroll
-            for (int r = 1; r < 16; r++) tw3[r - 1] = chz_twiddle(r * lane, 1024);
+            for (int r = 1; r < 16; r++) tw3[r - 1] = chz_twiddle(r * p3_i, 1024);
         }
         __syncthreads();                                          // all roles start together 
         {
@@ -773,7 +788,7 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
                 CHZ_STAMP(i, 0);
                 if (h >= 0 && h < nh) chz_p2(buf + ((h & (CHZ_SLOTS - 1)) * NB + wf) * CHZ_FB, lane);
                 CHZ_STAMP(i, 1);
-                if constexpr (P3_WITH_P2) { if (h3 >= 0 && h3 < nh) chz_p3(buf + ((h3 & (CHZ_SLOTS - 1)) * NB + wf) * CHZ_FB, tw3, lane); }
+                if constexpr (P3_WITH_P2) { if (h3 >= 0 && h3 < nh && p3_on) chz_p3(buf + ((h3 & (CHZ_SLOTS - 1)) * NB + p3_f) * CHZ_FB, tw3, p3_i); }
                 CHZ_STAMP(i, 3);
                 __syncthreads();
                 CHZ_STAMP(i, 4);
@@ -785,7 +800,7 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
         cf2 tw3[P3_WITH_P2 ? 1 : 15];                             // twiddles of the second radix-16 pass: W_1024^{r lane}
         if constexpr (!P3_WITH_P2) {
 #pragma unroll
-            for (int r = 1; r < 16; r++) tw3[r - 1] = chz_twiddle(r * lane, 1024);
+            for (int r = 1; r < 16; r++) tw3[r - 1] = chz_twiddle(r * p3_i, 1024);
         }
         ChzSlicer<SL, IQ, 0, 2> slicer;
         slicer.init(a, wf, lane);
@@ -796,7 +811,7 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
                 CHZ_STAMP(i, 0);
                 if (hs >= 0 && hs < nh) slicer.half(a, buf, fs, f0, f1, hs);
                 CHZ_STAMP(i, 1);
-                if constexpr (!P3_WITH_P2) { if (h3 >= 0 && h3 < nh) chz_p3(buf + ((h3 & (CHZ_SLOTS - 1)) * NB + wf) * CHZ_FB, tw3, lane); }
+                if constexpr (!P3_WITH_P2) { if (h3 >= 0 && h3 < nh && p3_on) chz_p3(buf + ((h3 & (CHZ_SLOTS - 1)) * NB + p3_f) * CHZ_FB, tw3, p3_i); }
                 CHZ_STAMP(i, 3);
                 __syncthreads();
                 CHZ_STAMP(i, 4);
@@ -827,7 +842,10 @@ __global__ __launch_bounds__(256) void chz_carry_kernel(const float2 *block, con
 struct ChannelizerState {
     bool enabled = false;
     int P = 8;
-    uint32_t C = 0, first_bin = 0;
+    uint32_t C = 0, first_bin = 0;  // rows this handle decodes (= the band's channels, or one group of them), FFT bin of the band's channel 0
+    uint32_t groups = 1, group = 0; // cfg.wideband_groups / wideband_group
+    uint16_t *bin2row = nullptr;    // device [M]
+    std::vector<uint32_t> row2chan; // row -> channel number within the band selection (what the records carry)
     uint32_t max_frames = 0;        // per push
     uint32_t target_wgs = 256;      // resident workgroups of the filter-bank kernel (one 768-thread workgroup per CU)
     float *taps = nullptr;          // [L]
@@ -889,9 +907,30 @@ inline int channelizer_reset(ChannelizerState &z, hipStream_t s)
 inline void channelizer_destroy(ChannelizerState &z)
 {
     z.stage_fence.destroy();
-    void *bufs[] = { z.taps, z.carry[0], z.carry[1], z.out, z.stage };
+    void *bufs[] = { z.taps, z.carry[0], z.carry[1], z.out, z.stage, z.bin2row };
     for (void *p : bufs) if (p) (void)hipFree(p);
     z = ChannelizerState();
+}
+
+// bins and rows of a handle: row i = the i-th channel (in band order) of the band selection [first, first + n) that belongs to the
+// handle's group -- all of them without groups.  Returns the row count, or a negative errno for an invalid split.
+inline int chz_rows(const amps_recc_cfg_t &cfg, std::vector<uint16_t> *bin2row, std::vector<uint32_t> *row2chan)
+{
+    const uint32_t G = cfg.wideband_groups > 1 ? cfg.wideband_groups : 1u;
+    if ((G != 1 && G != 2 && G != 4 && G != 8) || cfg.wideband_group >= G) return -EINVAL;
+    if (cfg.n_channels > (uint32_t)CHZ_M || cfg.wideband_first_channel >= (uint32_t)CHZ_M) return -EINVAL;
+    const uint32_t W = 64u / G;
+    if (bin2row) bin2row->assign(CHZ_M, (uint16_t)0xffffu);
+    if (row2chan) row2chan->clear();
+    uint32_t rows = 0;
+    for (uint32_t c = 0; c < cfg.n_channels; c++) {
+        const uint32_t k = (cfg.wideband_first_channel + c) & (CHZ_M - 1);
+        if ((k & 63u) / W != cfg.wideband_group) continue;
+        if (bin2row) (*bin2row)[k] = (uint16_t)rows;
+        if (row2chan) row2chan->push_back(c);
+        rows++;
+    }
+    return (int)rows;
 }
 
 inline int channelizer_create(ChannelizerState &z, const amps_recc_cfg_t &cfg, hipStream_t s)
@@ -900,7 +939,13 @@ inline int channelizer_create(ChannelizerState &z, const amps_recc_cfg_t &cfg, h
     const int P = cfg.wideband_taps_per_branch ? (int)cfg.wideband_taps_per_branch : 8;
     if (P != 8) return -EINVAL;                                   // the register ring of chz12_kernel is laid out for eight taps per branch
     if (cfg.n_channels > CHZ_M || cfg.wideband_first_channel >= CHZ_M || cfg.max_samples_per_push == 0) return -EINVAL;
-    z.P = P; z.C = cfg.n_channels; z.first_bin = cfg.wideband_first_channel;
+    std::vector<uint16_t> b2r;
+    const int rows = chz_rows(cfg, &b2r, &z.row2chan);
+    if (rows < 1) return rows < 0 ? rows : -EINVAL;
+    z.P = P; z.C = (uint32_t)rows; z.first_bin = cfg.wideband_first_channel;
+    z.groups = cfg.wideband_groups > 1 ? cfg.wideband_groups : 1u; z.group = cfg.wideband_group;
+    if (hipMalloc((void **)&z.bin2row, sizeof(uint16_t) * CHZ_M) != hipSuccess) return -ENOMEM;
+    if (hipMemcpy(z.bin2row, b2r.data(), sizeof(uint16_t) * CHZ_M, hipMemcpyHostToDevice) != hipSuccess) return -EIO;
     z.max_frames = cfg.max_samples_per_push;
     z.ld = ((uint64_t)z.max_frames + 7) & ~7ull;
     const size_t L = (size_t)P * CHZ_M;
@@ -932,6 +977,7 @@ inline int channelizer_run(ChannelizerState &z, const float2 *iq, size_t nsamp, 
                            int slicer = AMPS_SLICER_ATAN_BOXCAR, void (*after_main)(void *) = nullptr, void *after_ctx = nullptr)
 {
     if (!z.enabled) return -ENOSYS;
+    if (!fused && z.groups > 1) return -ENOSYS;                   // channel groups exist in the fused form only
     const float2 *d = iq;
     if (mem == AMPS_MEM_HOST) {
         if (int rc = z.stage_fence.wait()) return rc;             // the previous push may still be reading the staging buffer
@@ -965,6 +1011,7 @@ inline int channelizer_run(ChannelizerState &z, const float2 *iq, size_t nsamp, 
         uint32_t fpw = std::max<uint32_t>(64u, (nframes + z.target_wgs - 1) / z.target_wgs);
         fpw = (fpw + 63) / 64 * 64;
         a.frames_per_wg = fpw; a.first_bin = z.first_bin; a.n_channels = z.C;
+        a.bin2row = z.bin2row; a.grp_w = 64u / z.groups; a.grp_r = z.group;
         a.odd_start = 0;
         a.gring = gring; a.ring_words = ring_words; a.n_done = n_done;
         a.stream_start = z.frames_done == 0 ? 1u : 0u;

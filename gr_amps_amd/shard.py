@@ -21,6 +21,17 @@ def shard_table(n_items, world):
     return [shard_range(n_items, r, world) for r in range(world)]
 
 
+def group_channels(n_channels, first_bin, groups, group, m=1024):
+    """Channels (band numbering, ascending) of interleaved channel group `group` of `groups` -- cfg.wideband_groups of the C ABI: the
+    channels whose FFT bin k = (first_bin + c) mod m has (k mod 64) in [group * 64/groups, (group + 1) * 64/groups).  The one-band
+    multi-GPU split: every rank folds the whole wideband stream, but runs the last FFT pass, the slicer and everything behind them
+    for its own group only (include/amps_recc.h; bench.py --dist broadcast / --groups)."""
+    if groups not in (1, 2, 4, 8) or not 0 <= group < groups:
+        raise ValueError("groups must be 1, 2, 4 or 8 and 0 <= group < groups")
+    w = 64 // groups
+    return [c for c in range(n_channels) if (((first_bin + c) % m) % 64) // w == group]
+
+
 def broadcast_block(block, src=0, group=None):
     """Broadcast a torch tensor (the shared IQ block) from `src` to every rank, in place."""
     import torch.distributed as dist

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define AMPS_RECC_ABI_VERSION 1
+#define AMPS_RECC_ABI_VERSION 2   /* 2: amps_recc_cfg_t gained wideband_groups / wideband_group */
 
 /* protocol constants of the reference */
 #define AMPS_RECC_TRIGGER_SYMS 74   /* lib/recc_impl.cc:76-77: 37 bits x 2 Manchester symbols   */
@@ -147,6 +147,14 @@ typedef struct amps_recc_cfg {
     uint32_t sync_tolerance;       /* IQ / wideband seams: accept a trigger with up to this many of its 74
                                     * symbols wrong.  0 = exact match, the reference's memmem
                                     * (lib/recc_impl.cc:118) -- keep 0 for parity runs.  <= AMPS_RECC_MAX_SYNC_TOLERANCE */
+    uint32_t wideband_groups;      /* channelizer seam: 0 / 1 = this handle decodes the whole band selection; G = 2, 4 or 8 = the band's
+                                    * channels are split into G interleaved groups and this handle decodes ONE of them (one handle per
+                                    * GPU of a node, every one fed the same wideband stream: BASELINE configs[4]).  Group r = the active
+                                    * channels whose FFT bin k has (k mod 64) in [r * 64/G, (r+1) * 64/G): blocks of 64/G adjacent channels,
+                                    * every 64 -- the split that lets a rank skip the last FFT pass and the slicer for everybody else's
+                                    * bins.  n_channels / wideband_first_channel still describe the WHOLE band selection; records carry
+                                    * whole-band channel numbers; fused form only                                                    */
+    uint32_t wideband_group;       /* channelizer seam: which group, 0 .. wideband_groups - 1                                          */
     void    *stream;               /* hipStream_t to launch on, NULL = library-owned stream               */
 } amps_recc_cfg_t;
 

@@ -28,6 +28,21 @@ def test_shard_range_partitions_exactly():
     assert shard.shard_table(832, 8) == [(104 * r, 104 * (r + 1)) for r in range(8)]
 
 
+def test_channel_groups_partition_the_band():
+    """cfg.wideband_groups: G interleaved groups of the 832-channel band from bin 96 -- disjoint, complete, near-equal, and made of
+    runs of 64 / G adjacent channels (what lets a rank's FFT pass 3 keep 64 / G of its 64 lanes)"""
+    from gr_amps_amd import shard
+    for G in (1, 2, 4, 8):
+        parts = [shard.group_channels(832, 96, G, r) for r in range(G)]
+        assert sorted(c for p in parts for c in p) == list(range(832))
+        assert max(map(len, parts)) - min(map(len, parts)) <= 64 // G
+        for r, p in enumerate(parts):
+            assert all((((96 + c) % 1024) % 64) // (64 // G) == r for c in p)
+    assert [len(shard.group_channels(832, 96, 8, r)) for r in range(8)] == [104] * 8
+    with pytest.raises(ValueError):
+        shard.group_channels(832, 96, 3, 0)
+
+
 def _worker(rank, world, port, mode, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
