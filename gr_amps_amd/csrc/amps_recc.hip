@@ -65,8 +65,7 @@ struct amps_recc {
     uint64_t *det = nullptr;
     uint32_t *detcount = nullptr;
     uint64_t *next_allowed = nullptr, *pending = nullptr;
-    uint64_t *capq = nullptr;
-    uint32_t *capq_count = nullptr;
+    uint32_t *done_blocks = nullptr;              // resolve workgroups of the launch in flight that have finished
     amps_recc_burst_t *records = nullptr;
     uint32_t *nrecords = nullptr;
     uint32_t *status = nullptr;
@@ -217,7 +216,7 @@ int reset_state(amps_recc *h)
         HIP_TRY(hipMemsetAsync(h->detcount, 0, sizeof(uint32_t) * (size_t)h->C * h->max_chunks, s));
         HIP_TRY(hipMemsetAsync(h->next_allowed, 0, sizeof(uint64_t) * h->C, s));
         HIP_TRY(hipMemsetAsync(h->pending, 0xff, sizeof(uint64_t) * h->C, s));
-        HIP_TRY(hipMemsetAsync(h->capq_count, 0, 2 * sizeof(uint32_t), s));   // {queue count, finished capture workgroups}
+        HIP_TRY(hipMemsetAsync(h->done_blocks, 0, sizeof(uint32_t), s));
     }
     for (int b = 0; b < 2; b++) {
         HIP_TRY(hipMemsetAsync(h->nrecords_buf[b], 0, 2 * sizeof(uint32_t), s));
@@ -356,7 +355,7 @@ int dispatch_front(uint32_t sps, const FrontArgs &fa, dim3 grid, hipStream_t s, 
 void front_housekeeping_args(amps_recc *h, FrontArgs &fa)
 {
     h->open_untouched = false;              // this launch may clear the counters of the list a split drain has open
-    fa.zero1 = h->capq_count;
+    fa.zero1 = nullptr;
     const int idle = h->cur_buf ^ 1;
     fa.zero2 = h->list_clean[idle] ? nullptr : h->nrecords_buf[idle];
     h->list_clean[idle] = true;
@@ -365,12 +364,19 @@ void front_housekeeping_args(amps_recc *h, FrontArgs &fa)
 
 // the fused chain on channel-major device IQ: front -> carry -> resolve -> capture/decode
 // one workgroup per channel; wide groups when a channel spans more wave segments than 256 lanes cover in one batch
-static void launch_resolve(amps_recc *h, const ResolveArgs &ra, hipStream_t s)
+static void launch_resolve(amps_recc *h, ResolveArgs &ra, hipStream_t s)
 {
+    // capture + decode side of the kernel
+    ra.gring = h->gring; ra.ring_mask = h->ring_words - 1; ra.ring_words = h->ring_words; ra.cap_words = resolve_cap_words(h->sps);
+    ra.records = h->records; ra.nrecords = h->nrecords; ra.rec_cap = h->cfg.max_bursts; ra.status = h->status;
+    ra.majority = (h->cfg.flags & AMPS_RECC_FLAG_MAJORITY) ? 1u : 0u;
+    ra.burst_syms = h->bsym_dev_buf[h->cur_buf];
+    ra.done_blocks = h->done_blocks; ra.hdr_host = h->hdr_dev + HDR_STRIDE * h->cur_buf;
+    const size_t lds = resolve_dyn_lds(h->sps);
     if (ra.tiles_per_channel / ra.span + 2 > (uint64_t)RESOLVE_THREADS)
-        hipLaunchKernelGGL((recc_resolve_kernel<RESOLVE_THREADS_WIDE, RESOLVE_LDS_HITS_WIDE>), dim3(h->C), dim3(RESOLVE_THREADS_WIDE), 0, s, ra);
+        hipLaunchKernelGGL((recc_resolve_kernel<RESOLVE_THREADS_WIDE, RESOLVE_LDS_HITS_WIDE>), dim3(h->C), dim3(RESOLVE_THREADS_WIDE), lds, s, ra);
     else
-        hipLaunchKernelGGL((recc_resolve_kernel<RESOLVE_THREADS, RESOLVE_LDS_HITS>), dim3(h->C), dim3(RESOLVE_THREADS), 0, s, ra);
+        hipLaunchKernelGGL((recc_resolve_kernel<RESOLVE_THREADS, RESOLVE_LDS_HITS>), dim3(h->C), dim3(RESOLVE_THREADS), lds, s, ra);
 }
 
 int run_iq_device(amps_recc *h, const float2 *iq, uint64_t ld, uint32_t nsamp)
@@ -417,26 +423,12 @@ int run_iq_device(amps_recc *h, const float2 *iq, uint64_t ld, uint32_t nsamp)
         ResolveArgs ra{};
         ra.det = h->det; ra.detcount = h->detcount; ra.max_chunks = h->max_chunks; ra.det_cap = h->det_cap;
         ra.tiles_per_channel = Tc; ra.span = span; ra.sps = h->sps; ra.n_proc = h->n_done + P;
-        ra.next_allowed = h->next_allowed; ra.pending = h->pending; ra.capq = h->capq; ra.capq_count = h->capq_count;
-        ra.capq_cap = h->cfg.max_bursts; ra.status = h->status;
+        ra.next_allowed = h->next_allowed; ra.pending = h->pending;
         {
             SpanGuard g(h, T_RESOLVE);
             launch_resolve(h, ra, s);
         }
-        if (int rc = debug_sync(h, "resolve")) return rc;
-        CaptureArgs ca{};
-        ca.capq = h->capq; ca.capq_count = h->capq_count; ca.capq_cap = h->cfg.max_bursts; ca.sps = h->sps;
-        ca.gring = h->gring; ca.ring_mask = h->ring_words - 1; ca.ring_words = h->ring_words;
-        ca.records = h->records; ca.nrecords = h->nrecords; ca.rec_cap = h->cfg.max_bursts; ca.status = h->status;
-        ca.majority = (h->cfg.flags & AMPS_RECC_FLAG_MAJORITY) ? 1u : 0u;
-        ca.burst_syms = h->bsym_dev_buf[h->cur_buf];
-        ca.done_blocks = h->capq_count + 1; ca.hdr_host = h->hdr_dev + HDR_STRIDE * h->cur_buf;
-        {
-            SpanGuard g(h, T_DECODE);
-            uint32_t grid = std::min<uint32_t>(h->cfg.max_bursts, 2048u);
-            hipLaunchKernelGGL(recc_capture_kernel, dim3(grid), dim3(64), 0, s, ca);
-        }
-        if (int rc = debug_sync(h, "capture")) return rc;
+        if (int rc = debug_sync(h, "resolve + capture")) return rc;
     }
     HIP_TRY(hipGetLastError());
     h->n_done += P;
@@ -574,8 +566,7 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
         rc |= dev_alloc(&h->detcount, C * h->max_chunks);
         rc |= dev_alloc(&h->next_allowed, C);
         rc |= dev_alloc(&h->pending, C);
-        rc |= dev_alloc(&h->capq, cfg->max_bursts);
-        rc |= dev_alloc(&h->capq_count, 2);     // {queue count, finished capture workgroups}
+        rc |= dev_alloc(&h->done_blocks, 1);
     }
     if (!rc && cfg->wideband_channels) rc = channelizer_create(h->chz, *cfg, h->stream);
     if (!rc) rc = reset_state(h);
@@ -593,8 +584,8 @@ void amps_recc_destroy(amps_recc_t *h)
     h->stage_iq_fence.destroy();
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
     h->event_pool.clear();
-    void *bufs[] = { h->carry[0], h->carry[1], h->gring, h->det, h->detcount, h->next_allowed, h->pending, h->capq,
-                     h->capq_count, h->nrecords_buf[0], h->nrecords_buf[1], h->stage_iq, h->symbuf, h->sym_len, h->sym_cur,
+    void *bufs[] = { h->carry[0], h->carry[1], h->gring, h->det, h->detcount, h->next_allowed, h->pending,
+                     h->done_blocks, h->nrecords_buf[0], h->nrecords_buf[1], h->stage_iq, h->symbuf, h->sym_len, h->sym_cur,
                      h->sym_stage, h->bursts_dev, h->burst_chan_dev, h->nbursts_dev, h->dec_out_dev, h->dec_in_dev,
                      h->dec_chan_dev, h->dbg_d, h->dbg_S, h->bch_in, h->bch_out, h->bch_val, h->bch_err };
     for (void *p : bufs) if (p) (void)hipFree(p);
@@ -771,22 +762,10 @@ int run_bits_device(amps_recc *h, uint32_t P)
     ResolveArgs ra{};
     ra.det = h->det; ra.detcount = h->detcount; ra.max_chunks = h->max_chunks; ra.det_cap = h->det_cap;
     ra.tiles_per_channel = Tc; ra.span = span; ra.sps = h->sps; ra.n_proc = h->n_done + P;
-    ra.next_allowed = h->next_allowed; ra.pending = h->pending; ra.capq = h->capq; ra.capq_count = h->capq_count;
-    ra.capq_cap = h->cfg.max_bursts; ra.status = h->status;
+    ra.next_allowed = h->next_allowed; ra.pending = h->pending;
     {
         SpanGuard g(h, T_RESOLVE);
         launch_resolve(h, ra, s);
-    }
-    CaptureArgs ca{};
-    ca.capq = h->capq; ca.capq_count = h->capq_count; ca.capq_cap = h->cfg.max_bursts; ca.sps = h->sps;
-    ca.gring = h->gring; ca.ring_mask = h->ring_words - 1; ca.ring_words = h->ring_words;
-    ca.records = h->records; ca.nrecords = h->nrecords; ca.rec_cap = h->cfg.max_bursts; ca.status = h->status;
-    ca.majority = (h->cfg.flags & AMPS_RECC_FLAG_MAJORITY) ? 1u : 0u;
-    ca.burst_syms = h->bsym_dev_buf[h->cur_buf];
-    ca.done_blocks = h->capq_count + 1; ca.hdr_host = h->hdr_dev + HDR_STRIDE * h->cur_buf;
-    {
-        SpanGuard g(h, T_DECODE);
-        hipLaunchKernelGGL(recc_capture_kernel, dim3(std::min<uint32_t>(h->cfg.max_bursts, 2048u)), dim3(64), 0, s, ca);
     }
     HIP_TRY(hipGetLastError());
     h->n_done += P;

@@ -103,6 +103,8 @@ __global__ __launch_bounds__(256) void recc_bits_kernel(FrontArgs a)
                 }
             };
 
+            // one block fetched ahead is enough: the kernel is bound by instruction issue (~90 wave instructions per 2048 positions),
+            // four blocks in flight made it 30 % slower (profiles/EXPERIMENTS.md)
             uint32_t wnext = load_word(d_first + lane);                  // block 0, fetched ahead
             uint32_t hist0 = lane < K ? load_word(d_first - K + lane) : 0u;
             uint32_t m_prev = 0, m_prev_before = 0;                      // block t-1 (lane's word) and the word before its lane 0

@@ -103,35 +103,48 @@ __device__ __forceinline__ BchResult bch63_decode_packed(uint64_t w)
         S3 |= (unsigned)(__popcll(w & k_syn.m3[k]) & 1) << k;
     }
     if ((S1 | S3) == 0) { r.ok = 1; return r; }
+    // the root searches keep their (up to three) results in named registers: an array indexed by the running count lands in
+    // scratch memory (260 scratch instructions in the first version of this kernel, each a trip to HBM on the latency path)
+    int found = 0, e0 = -1, e1 = -1, e2 = -1;
+    auto take = [&](bool root, int j) {
+        const int pos = (63 - j) % 63;
+        e0 = (root && found == 0) ? pos : e0;
+        e1 = (root && found == 1) ? pos : e1;
+        e2 = (root && found == 2) ? pos : e2;
+        found += (root && found < 3) ? 1 : 0;
+    };
     if (S1 != 0) {
         const unsigned S1cube = gf_mul(gf_mul(S1, S1), S1);
         const unsigned delta = S3 ^ S1cube;      // Omega[3] = S3 + S1*S2, S2 = S1^2
         if (delta == 0) {                        // Lambda = 1 + S1 x : single error at log(S1)
             unsigned p = 1;
             int lg = 0;
+#pragma unroll 1
             for (int j = 0; j < 63; j++) { if (p == S1) lg = j; p = gf_xtime(p); }
             r.ok = 1; r.nflip = 1; r.e[0] = lg;
             return r;
         }
         const unsigned c2 = gf_div(delta, S1);   // Lambda = 1 + S1 x + (delta/S1) x^2
-        int found = 0;
         unsigned a = S1, b = c2;                 // S1 alpha^j, c2 alpha^(2j)
+#pragma unroll 1
         for (int j = 0; j < 63; j++) {
-            if ((1u ^ a ^ b) == 0 && found < 3) r.e[found++] = (63 - j) % 63;
+            take((1u ^ a ^ b) == 0, j);
             a = gf_xtime(a);
             b = gf_xtime(gf_xtime(b));
         }
+        r.e[0] = e0; r.e[1] = e1; r.e[2] = e2;
         if (found == 2) { r.ok = 1; r.nflip = 2; }
         return r;
     }
     // S1 == 0, S3 != 0: first step leaves Lambda = 1 and T = x^2, second gives Lambda = 1 + S3 x^3
     {
-        int found = 0;
         unsigned c = S3;                         // S3 alpha^(3j)
+#pragma unroll 1
         for (int j = 0; j < 63; j++) {
-            if ((1u ^ c) == 0 && found < 3) r.e[found++] = (63 - j) % 63;
+            take((1u ^ c) == 0, j);
             c = gf_xtime(gf_xtime(gf_xtime(c)));
         }
+        r.e[0] = e0; r.e[1] = e1; r.e[2] = e2;
         if (found == 3) { r.ok = 1; r.nflip = 3; }
     }
     return r;
@@ -193,53 +206,101 @@ __device__ __forceinline__ void extract_min_3(unsigned val, char *out)
     out[0] = (char)('0' + dig);
 }
 
-// LDS scratch one wave needs to decode a burst
+// LDS scratch one wave needs to decode a burst.  DecodeCore is everything behind the Manchester stage; the symbol bytes are only
+// staged when the burst arrives as bytes (amps_recc_decode_bursts) -- a capture out of the slicer-bit ring goes from ring words
+// to Manchester bits directly (recc_resolve.hip.h).
 constexpr int BOFF = 1;                         // bit k of the burst lives at bits[BOFF + k]: the word blocks start at 8 + 240 w + 48 r
-struct DecodeScratch {
-    uint8_t  sym[AMPS_RECC_CAPTURE_SYMS + 2];   // symbol bytes
-    uint8_t  bits[1696];                        // [BOFF + k], k < 7 + 7*240: dcc(7) then the words; BOFF makes every 48-bit block 8-byte aligned
+struct DecodeCore {
+    alignas(8) uint8_t bits[1696];              // [BOFF + k], k < 7 + 7*240: dcc(7) then the words; BOFF makes every 48-bit block 8-byte aligned
+    uint64_t packed[7];                         // the words the field parser reads, bit-reversed: bit 63-i = word bit i
     uint32_t bad[8];                            // [0]=dcc, [1+w]=word w
     uint32_t nonbin;
     int8_t   ok[35];
     int8_t   flip[35][3];
     int8_t   rr[8];                             // repeat whose bits become word_dec[w]
-    uint64_t packed[7];                         // the words the field parser reads, bit-reversed: bit 63-i = word bit i
     amps_recc_burst_t rec;                      // staged record (728 B), copied out coalesced
 };
+struct DecodeScratch {
+    DecodeCore k;
+    uint8_t sym[AMPS_RECC_CAPTURE_SYMS + 2];    // symbol bytes
+};
 
-// Decode the burst held in s.sym; all 64 lanes of ONE wave must call this (blockDim.x == 64).
-__device__ __forceinline__ void decode_burst_wave(DecodeScratch &s, uint32_t channel, uint64_t position,
-                                         amps_recc_burst_t *__restrict__ out, bool majority = false)
+// Synchronisation of the lanes that decode one burst: a whole (single-wave) workgroup, or one wave of a larger workgroup --
+// LDS operations of one wave complete in issue order, so there only the compiler has to be kept from moving them.
+struct BlockSync { static __device__ __forceinline__ void sync() { __syncthreads(); } };
+struct WaveSync {
+    static __device__ __forceinline__ void sync()
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+};
+
+// clear the per-burst counters and the staged record (all 64 lanes of the wave; followed by a sync in the Manchester stage)
+__device__ __forceinline__ void decode_core_begin(DecodeCore &s, int lane)
 {
-    const int lane = threadIdx.x & 63;
     if (lane < 8) s.bad[lane] = 0;
     if (lane == 8) s.nonbin = 0;
-    // zero the staged record
     for (int i = lane; i < (int)(sizeof(amps_recc_burst_t) / 4); i += 64) ((uint32_t *)&s.rec)[i] = 0;
-    __syncthreads();
+}
 
-    // ---- Manchester decode, lib/utils.cc:27-59: (1,0) -> 0, (0,1) -> 1, (1,1) -> 0 + bad, (0,0) -> 1 + bad; a byte outside
-    // {0,1} is undefined in the reference (assert(0) compiled out): bit 0 + bad + flag.  Branch-free on one 16-bit read per
-    // pair so the 27 rounds pipeline (the four-way if/else with byte reads cost 5 us per burst).
-    {
-        const uint16_t *s16 = (const uint16_t *)s.sym;
+// ---- Manchester decode, lib/utils.cc:27-59: (1,0) -> 0, (0,1) -> 1, (1,1) -> 0 + bad, (0,0) -> 1 + bad; a byte outside
+// {0,1} is undefined in the reference (assert(0) compiled out): bit 0 + bad + flag.  Branch-free on one 16-bit read per
+// pair so the 27 rounds pipeline (the four-way if/else with byte reads cost 5 us per burst).
+template <class Sync>
+__device__ __forceinline__ void manchester_from_sym(DecodeCore &s, const uint8_t *sym, int lane)
+{
+    decode_core_begin(s, lane);
+    Sync::sync();
+    const uint16_t *s16 = (const uint16_t *)sym;
 #pragma unroll 9
-        for (int it = 0; it < 27; it++) {
-            const int k = lane + 64 * it;
-            if (k < 1687) {
-                const unsigned pr = s16[k];
-                const unsigned sa = pr & 0xffu, sb = pr >> 8;
-                const bool nonbin = (sa | sb) > 1u;
-                const bool same = sa == sb;
-                const unsigned bit = nonbin ? 0u : (same ? (sa ^ 1u) : sb);
-                s.bits[BOFF + k] = (uint8_t)bit;
-                if (nonbin) atomicOr(&s.nonbin, 1u);
-                if (nonbin || same) atomicAdd(&s.bad[k < 7 ? 0 : 1 + (k - 7) / 240], 1u);
-            }
+    for (int it = 0; it < 27; it++) {
+        const int k = lane + 64 * it;
+        if (k < 1687) {
+            const unsigned pr = s16[k];
+            const unsigned sa = pr & 0xffu, sb = pr >> 8;
+            const bool nonbin = (sa | sb) > 1u;
+            const bool same = sa == sb;
+            const unsigned bit = nonbin ? 0u : (same ? (sa ^ 1u) : sb);
+            s.bits[BOFF + k] = (uint8_t)bit;
+            if (nonbin) atomicOr(&s.nonbin, 1u);
+            if (nonbin || same) atomicAdd(&s.bad[k < 7 ? 0 : 1 + (k - 7) / 240], 1u);
         }
     }
-    __syncthreads();
+    Sync::sync();
+}
 
+// The same straight from slicer bits: symbol i of the capture is bit nc + sps (i + 1) of the channel's stream; `ring` holds
+// the stream's 64-bit words from word w0 on (LDS).  Bits cannot be non-binary.
+template <class Sync>
+__device__ __forceinline__ void manchester_from_ring(DecodeCore &s, const uint64_t *ring, uint64_t nc, uint64_t w0, uint32_t sps, int lane)
+{
+    decode_core_begin(s, lane);
+    Sync::sync();
+    const uint32_t *r32 = (const uint32_t *)ring;
+    const uint64_t base = nc + sps - (w0 << 6);                 // bit offset of symbol 0 inside the window (< 2^20)
+#pragma unroll 9
+    for (int it = 0; it < 27; it++) {
+        const int k = lane + 64 * it;
+        if (k < 1687) {
+            const uint32_t na = (uint32_t)base + sps * (uint32_t)(2 * k), nb = na + sps;
+            const unsigned sa = (r32[na >> 5] >> (na & 31)) & 1u, sb = (r32[nb >> 5] >> (nb & 31)) & 1u;
+            const bool same = sa == sb;
+            s.bits[BOFF + k] = (uint8_t)(same ? (sa ^ 1u) : sb);
+            if (same) atomicAdd(&s.bad[k < 7 ? 0 : 1 + (k - 7) / 240], 1u);
+        }
+    }
+    Sync::sync();
+}
+
+// BCH + first-valid-repeat + field parse + record write of the burst whose Manchester bits are in s.bits; all 64 lanes of ONE wave.
+// Tl: optional stage stamps (scripts/ubench_decode.hip); NoTl compiles to nothing.
+struct NoTl { __device__ __forceinline__ void mark(int) {} };
+template <class Sync, class Tl = NoTl>
+__device__ __forceinline__ void decode_core_wave(DecodeCore &s, uint32_t channel, uint64_t position,
+                                                 amps_recc_burst_t *__restrict__ out, bool majority, int lane, Tl tl = Tl())
+{
     amps_recc_burst_t &o = s.rec;
     if (!majority) {
         // ---- BCH: 7 words x 5 repeats, lib/recc_decode_impl.cc:100-107 ----
@@ -251,7 +312,8 @@ __device__ __forceinline__ void decode_burst_wave(DecodeScratch &s, uint32_t cha
             s.flip[lane][1] = (int8_t)br.e[1];
             s.flip[lane][2] = (int8_t)br.e[2];
         }
-        __syncthreads();
+        Sync::sync();
+        tl.mark(1);
         if (lane < 7) {
             const int w = lane;
             int r = 0, ok = 0;
@@ -263,13 +325,15 @@ __device__ __forceinline__ void decode_burst_wave(DecodeScratch &s, uint32_t cha
         }
         // raw repeat 0 of every word (what the reference parses)
         for (int i = lane; i < 7 * 48; i += 64) o.word_raw[i / 48][i % 48] = s.bits[BOFF + 7 + 240 * (i / 48) + (i % 48)];
-        __syncthreads();
+        Sync::sync();
+        tl.mark(2);
         // word_dec = the 36 message bits of the first valid repeat (or of repeat 4), copied by all lanes, then corrected
         for (int i = lane; i < 7 * 36; i += 64) {
             const int w = i / 36, b = i % 36;
             o.word_dec[w][b] = s.bits[BOFF + 7 + 240 * w + 48 * s.rr[w] + b];
         }
-        __syncthreads();
+        Sync::sync();
+        tl.mark(3);
         if (lane < 7 && o.valid[lane]) {
             const int w = lane;
             for (int f = 0; f < 3; f++) {
@@ -285,7 +349,7 @@ __device__ __forceinline__ void decode_burst_wave(DecodeScratch &s, uint32_t cha
             for (int r = 0; r < 5; r++) cnt += s.bits[BOFF + 7 + 240 * w + 48 * r + b];
             o.word_raw[w][b] = (uint8_t)(cnt >= 3);
         }
-        __syncthreads();
+        Sync::sync();
         if (lane < 7) {
             const int w = lane;
             BchResult br = bch4836_decode(o.word_raw[w]);
@@ -305,7 +369,8 @@ __device__ __forceinline__ void decode_burst_wave(DecodeScratch &s, uint32_t cha
         }
     }
     if (lane < 7) o.dcc[lane] = s.bits[BOFF + lane];
-    __syncthreads();
+    Sync::sync();
+    tl.mark(4);
     // pack the seven words the parser reads (one ballot each): the field extraction below is then shifts on registers
     // instead of ~250 dependent one-byte LDS reads by a single lane (7 us of a 25 us burst)
     for (int w = 0; w < 7; w++) {
@@ -314,7 +379,8 @@ __device__ __forceinline__ void decode_burst_wave(DecodeScratch &s, uint32_t cha
         const uint64_t m = __ballot(bit != 0);
         if (lane == 0) s.packed[w] = __brevll(m);
     }
-    __syncthreads();
+    Sync::sync();
+    tl.mark(5);
 
     // ---- field parse + dispatch: one lane, negligible work (lib/amps_packet.h, recc_decode_impl.cc:108-168) ----
     if (lane == 0) {
@@ -329,10 +395,8 @@ __device__ __forceinline__ void decode_burst_wave(DecodeScratch &s, uint32_t cha
         auto fld = [](uint64_t wp, int off, int n) -> unsigned { return (unsigned)((wp >> (64 - off - n)) & ((1ull << n) - 1ull)); };   // MSB first
         const uint64_t A = W(0), B = W(1);
         if (majority) {   // coded DCC: 0000000 / 0011111 / 1100011 / 1111100, accept within one bit
-            const unsigned codes[4] = { 0x00, 0x1f, 0x63, 0x7c };
-            unsigned d = getbits(o.dcc, 7);
-            bool good = false;
-            for (int i = 0; i < 4; i++) if (__popc(d ^ codes[i]) <= 1) good = true;
+            const unsigned d = getbits(o.dcc, 7);
+            const bool good = __popc(d ^ 0x00u) <= 1 || __popc(d ^ 0x1fu) <= 1 || __popc(d ^ 0x63u) <= 1 || __popc(d ^ 0x7cu) <= 1;
             if (!good) o.flags |= AMPS_BURST_FLAG_DCC_INVALID;
         }
         o.a_F = (uint8_t)fld(A, 0, 1); o.a_NAWC = (uint8_t)fld(A, 1, 3);
@@ -393,9 +457,20 @@ __device__ __forceinline__ void decode_burst_wave(DecodeScratch &s, uint32_t cha
         } else o.msg_class = AMPS_MSG_UNKNOWN;
         if (majority && !used_ok && o.msg_class >= AMPS_MSG_PAGE_RESPONSE) o.msg_class = AMPS_MSG_INVALID_WORD_A;
     }
-    __syncthreads();
+    Sync::sync();
+    tl.mark(6);
     // coalesced copy of the staged record to HBM
     for (int i = lane; i < (int)(sizeof(amps_recc_burst_t) / 4); i += 64) ((uint32_t *)out)[i] = ((const uint32_t *)&s.rec)[i];
+    tl.mark(7);
+}
+
+// Decode the burst held in s.sym; all 64 lanes of ONE single-wave workgroup must call this (blockDim.x == 64).
+__device__ __forceinline__ void decode_burst_wave(DecodeScratch &s, uint32_t channel, uint64_t position,
+                                                  amps_recc_burst_t *__restrict__ out, bool majority = false)
+{
+    const int lane = threadIdx.x & 63;
+    manchester_from_sym<BlockSync>(s.k, s.sym, lane);
+    decode_core_wave<BlockSync>(s.k, channel, position, out, majority, lane);
 }
 
 } // namespace amps

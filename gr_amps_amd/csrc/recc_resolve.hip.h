@@ -2,22 +2,21 @@
 //
 // What the reference does serially inside recc_impl::work once memmem has hit
 // (lib/recc_impl.cc:121-139: wait until more than 3374 symbols follow, publish them, resume the
-// search after the captured region) becomes two small kernels that run after the streaming front
-// kernel on the same stream:
-//   recc_resolve_kernel  one wave per channel: walks the channel's ordered hit list, drops hits that
-//                        fall inside an accepted burst (hold-off = 74+3374 symbols), picks the centre
-//                        of the run of matching sample phases as the symbol timing, and either queues
-//                        the capture or parks it as "pending" until its tail has been received.
-//   recc_capture_kernel  one wave per queued capture: gathers the 3374 slicer bits at the chosen
-//                        phase from the channel's HBM bit ring, then runs the recc_decode core
-//                        (recc_decode.hip.h) and appends the record.
-// Both are latency-bound bookkeeping on kilobytes; the HBM-bound work is in recc_front.hip.h.
+// search after the captured region) is ONE small kernel behind the streaming front kernel, one workgroup per channel
+// (everything here is channel-local):
+//   resolve   walks the channel's ordered hit list, drops hits that fall inside an accepted burst (hold-off = 74+3374
+//             symbols), picks the centre of the run of matching sample phases as the symbol timing, and either accepts
+//             the capture or parks it as "pending" until its tail has been received;
+//   capture   the workgroup's first CAP_WAVES waves each take accepted captures in turn: gather the 3374 slicer bits at the
+//             chosen phase from the channel's HBM bit ring, run the recc_decode core (recc_decode.hip.h), append the record.
+// (Round 2 had a capture queue and a second kernel of one workgroup per capture: 2048 workgroups to dispatch, a launch and
+// ~25 us per push for the same work.)  Latency-bound bookkeeping on kilobytes; the HBM-bound work is in recc_front.hip.h.
 #pragma once
 #include "recc_decode.hip.h"
 
 namespace amps {
 
-// a queued capture packs (channel, position): 2^44 samples per channel stream (2.8 years at 200 ksps) and 2^20 channels
+// the host sorts records by one packed key (channel, position): 2^44 samples per channel stream (2.8 years at 200 ksps), 2^20 channels
 constexpr int CAPQ_POS_BITS = 44;
 
 struct ResolveArgs {
@@ -29,12 +28,54 @@ struct ResolveArgs {
     uint64_t n_proc;           // absolute samples processed after this push
     uint64_t *next_allowed;    // [C]
     uint64_t *pending;         // [C], ~0 = none (holds n_c)
-    uint2    *capq_chan;       // unused
-    uint64_t *capq;            // [capq_cap] (channel << CAPQ_POS_BITS | n_c)
-    uint32_t *capq_count;      // atomic
-    uint32_t capq_cap;
-    uint32_t *status;          // bit 1: capture queue overflow
+    uint32_t *status;          // bit 2: record list overflow (bit 1, capture queue overflow, is no longer produced)
+    // capture + decode
+    const uint64_t *gring;
+    uint32_t ring_mask, ring_words;
+    uint32_t cap_words;        // ring words one capture spans at most: sizes the dynamic LDS (resolve_dyn_lds)
+    amps_recc_burst_t *records;
+    uint32_t *nrecords;        // atomic
+    uint32_t rec_cap;
+    uint32_t majority;         // decode mode (AMPS_RECC_FLAG_MAJORITY)
+    uint8_t *burst_syms;       // optional [rec_cap][3374]: the captured symbols of record `slot` (AMPS_RECC_FLAG_KEEP_BURSTS)
+    uint32_t *done_blocks;     // workgroups of this launch that have finished (the last one publishes the header and clears it)
+    uint32_t *hdr_host;        // mapped pinned {nrecords, status} of the record list: what a drain reads, no copy on the stream
 };
+
+constexpr int CAP_WAVES = 4;               // waves of a workgroup that decode captures side by side
+// dynamic LDS of the kernel: per decoding wave one DecodeCore and the ring words of one capture
+__host__ __device__ constexpr uint32_t resolve_cap_stride(uint32_t cap_words) { return (uint32_t)((sizeof(DecodeCore) + 7) / 8) + cap_words; }   // in 8-byte words
+inline uint32_t resolve_cap_words(uint32_t sps) { return (AMPS_RECC_CAPTURE_SYMS * sps) / 64 + 3; }
+inline size_t resolve_dyn_lds(uint32_t sps) { return (size_t)CAP_WAVES * resolve_cap_stride(resolve_cap_words(sps)) * 8; }
+
+// One accepted capture (channel c, symbol-timing position nc), by all 64 lanes of one wave.
+__device__ __forceinline__ void capture_decode_wave(const ResolveArgs &a, uint32_t c, uint64_t nc, uint64_t *scratch, int lane)
+{
+    DecodeCore &k = *(DecodeCore *)scratch;
+    uint64_t *s_ring = scratch + (sizeof(DecodeCore) + 7) / 8;
+    const uint64_t *ring = a.gring + (uint64_t)c * a.ring_words;
+    const uint64_t w0 = (nc + a.sps) >> 6;
+    const int nw = (int)(((nc + (uint64_t)a.sps * AMPS_RECC_CAPTURE_SYMS) >> 6) - w0) + 1;
+    for (int i = lane; i < nw; i += 64) s_ring[i] = ring[(w0 + (uint64_t)i) & a.ring_mask];
+    uint32_t slot = 0;
+    if (lane == 0) slot = atomicAdd(a.nrecords, 1u);
+    slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
+    if (slot >= a.rec_cap) {
+        if (lane == 0) { atomicOr(a.status, 4u); __threadfence(); }   // rare: performed before this workgroup counts itself done
+        return;
+    }
+    WaveSync::sync();
+    if (a.burst_syms) {
+        uint8_t *dst = a.burst_syms + (uint64_t)slot * AMPS_RECC_CAPTURE_SYMS;
+        for (int i = lane; i < AMPS_RECC_CAPTURE_SYMS; i += 64) {
+            const uint64_t n = nc + (uint64_t)a.sps * (uint64_t)(i + 1);
+            dst[i] = (uint8_t)((s_ring[(n >> 6) - w0] >> (n & 63)) & 1ull);
+        }
+    }
+    manchester_from_ring<WaveSync>(k, s_ring, nc, w0, a.sps, lane);
+    decode_core_wave<WaveSync>(k, c, nc, a.records + slot, a.majority != 0, lane);
+    WaveSync::sync();
+}
 
 constexpr int RESOLVE_THREADS = 256;       // many channels, few segments each
 constexpr int RESOLVE_THREADS_WIDE = 1024; // few channels, thousands of segments each (one channel x 2^26 samples)
@@ -48,35 +89,30 @@ constexpr int RESOLVE_LDS_HITS_WIDE = 2048;
 // A batch of THREADS segments with more hits than the LDS window holds is walked in several passes (the hold-off state
 // carries from pass to pass exactly as it does from batch to batch), so no hit count overflows this kernel.
 template <int THREADS, int HITS>
-__global__ __launch_bounds__(THREADS) void recc_resolve_kernel(ResolveArgs a)
+__global__ __launch_bounds__(THREADS, 4) void recc_resolve_kernel(ResolveArgs a)
 {
     __shared__ uint64_t s_hits[HITS];
-    __shared__ uint32_t s_scan[THREADS];
+    __shared__ uint32_t s_scan[THREADS / 64];                      // wave totals of the count scan
     __shared__ uint64_t s_acc[HITS + 1];                           // +1: the pending capture of an earlier push
     __shared__ uint8_t  s_head[HITS], s_accf[HITS];
     __shared__ uint64_t s_na_out, s_pend;
-    __shared__ uint32_t s_total, s_nacc, s_base;
+    __shared__ uint32_t s_total, s_nacc;
+    extern __shared__ uint64_t s_cap[];                            // [CAP_WAVES][resolve_cap_stride]
     const int c = blockIdx.x, tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const uint64_t span_hold = (uint64_t)a.sps * (AMPS_RECC_CAPTURE_SYMS + AMPS_RECC_TRIGGER_SYMS);
     const uint64_t span_done = (uint64_t)a.sps * (AMPS_RECC_CAPTURE_SYMS + 1);
     uint64_t next_allowed = a.next_allowed[c];                        // uniform across the block
     uint64_t pend = a.pending[c];
     auto centre = [](uint64_t ei) -> uint64_t { return (ei >> 8) + (uint32_t)(ei & 0xff) / 2; };   // of the run of matching phases
 
-    // accepted captures are collected in LDS and published with ONE atomicAdd per batch: a global atomic per burst
-    // is a ~0.4 us round trip
+    // accepted captures are collected in LDS; the first CAP_WAVES waves then capture and decode them, one each in turn
     auto flush = [&]() {                                              // all threads
         __syncthreads();
         const uint32_t m = s_nacc;
-        if (m) {
-            if (tid == 0) s_base = atomicAdd(a.capq_count, m);
-            __syncthreads();
-            const uint32_t base = s_base;
-            for (uint32_t i = tid; i < m; i += THREADS) {
-                if (base + i < a.capq_cap) a.capq[base + i] = ((uint64_t)c << CAPQ_POS_BITS) | (s_acc[i] & ((1ull << CAPQ_POS_BITS) - 1));
-                else atomicOr(a.status, 2u);
-            }
-        }
+        if (wv < CAP_WAVES)
+            for (uint32_t i = (uint32_t)wv; i < m; i += CAP_WAVES)
+                capture_decode_wave(a, (uint32_t)c, s_acc[i], s_cap + (size_t)wv * resolve_cap_stride(a.cap_words), lane);
         __syncthreads();
     };
     if (tid == 0) s_nacc = 0;
@@ -95,16 +131,19 @@ __global__ __launch_bounds__(THREADS) void recc_resolve_kernel(ResolveArgs a)
         // ---- compaction of up to THREADS segments into LDS, order preserved
         const uint32_t ch = cb + tid;
         const uint32_t n = ch < nchunks ? cnt[ch] : 0u;
-        s_scan[tid] = n;
-        __syncthreads();
-        for (int off = 1; off < THREADS; off <<= 1) {       // Hillis-Steele inclusive scan
-            uint32_t v = tid >= off ? s_scan[tid - off] : 0u;
-            __syncthreads();
-            s_scan[tid] += v;
-            __syncthreads();
+        // inclusive scan of the counts: inside each wave by lane shifts, then the wave totals (two barriers; the first version
+        // was a Hillis-Steele scan over the workgroup in LDS, seventeen)
+        uint32_t incl = n;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t y = (uint32_t)__shfl_up((int)incl, off);
+            if (lane >= off) incl += y;
         }
-        const uint32_t excl = s_scan[tid] - n;
-        if (tid == THREADS - 1) s_total = s_scan[tid];
+        if (lane == 63) s_scan[wv] = incl;
+        __syncthreads();
+        for (int w = 0; w < wv; w++) incl += s_scan[w];
+        const uint32_t excl = incl - n;
+        if (tid == THREADS - 1) s_total = incl;
         __syncthreads();
         const uint32_t batch_total = s_total;
         const uint64_t *d = det + (uint64_t)ch * a.det_cap;
@@ -155,71 +194,14 @@ __global__ __launch_bounds__(THREADS) void recc_resolve_kernel(ResolveArgs a)
             __syncthreads();
         }
     }
-    if (nchunks == 0) flush();
-    if (tid == 0) { a.next_allowed[c] = next_allowed; a.pending[c] = pend; }
-}
-
-struct CaptureArgs {
-    const uint64_t *capq;
-    const uint32_t *capq_count;
-    uint32_t capq_cap;
-    uint32_t sps;
-    const uint64_t *gring;
-    uint32_t ring_mask, ring_words;
-    amps_recc_burst_t *records;
-    uint32_t *nrecords;       // atomic
-    uint32_t rec_cap;
-    uint32_t *status;         // bit 2: record list overflow
-    uint32_t majority;        // decode mode (AMPS_RECC_FLAG_MAJORITY)
-    uint8_t *burst_syms;      // optional [rec_cap][3374]: the captured symbols of record `slot` (AMPS_RECC_FLAG_KEEP_BURSTS)
-    uint32_t *done_blocks;    // workgroups of this launch that have finished (the last one publishes the header and clears it)
-    uint32_t *hdr_host;       // mapped pinned {nrecords, status} of the record list: what a drain reads, no copy on the stream
-};
-
-__global__ __launch_bounds__(64) void recc_capture_kernel(CaptureArgs a)
-{
-    __shared__ DecodeScratch s;
-    __shared__ uint32_t s_slot;
-    // the capture spans 3374 * sps samples = at most 845 ring words (sps <= 16): fetched once, coalesced, into LDS; the
-    // first version had every lane fetch its 53 words one dependent 8-byte load at a time
-    constexpr int MAXW = (AMPS_RECC_CAPTURE_SYMS * 16) / 64 + 3;
-    __shared__ uint64_t s_ring[MAXW];
-    const int lane = threadIdx.x;
-    uint32_t ncap = *a.capq_count;
-    if (ncap > a.capq_cap) ncap = a.capq_cap;
-    for (uint32_t q = blockIdx.x; q < ncap; q += gridDim.x) {
-        const uint64_t e = a.capq[q];
-        const uint32_t c = (uint32_t)(e >> CAPQ_POS_BITS);
-        const uint64_t nc = e & ((1ull << CAPQ_POS_BITS) - 1);
-        const uint64_t *ring = a.gring + (uint64_t)c * a.ring_words;
-        const uint64_t w0 = (nc + a.sps) >> 6;
-        const int nw = (int)(((nc + (uint64_t)a.sps * AMPS_RECC_CAPTURE_SYMS) >> 6) - w0) + 1;
-        for (int i = lane; i < nw; i += 64) s_ring[i] = ring[(w0 + (uint64_t)i) & a.ring_mask];
-        __syncthreads();
-        for (int i = lane; i < AMPS_RECC_CAPTURE_SYMS; i += 64) {
-            const uint64_t n = nc + (uint64_t)a.sps * (uint64_t)(i + 1);
-            s.sym[i] = (uint8_t)((s_ring[(n >> 6) - w0] >> (n & 63)) & 1ull);
-        }
-        if (lane == 0) s_slot = atomicAdd(a.nrecords, 1u);
-        __syncthreads();
-        const uint32_t slot = s_slot;
-        if (slot < a.rec_cap && a.burst_syms) {
-            uint8_t *dst = a.burst_syms + (uint64_t)slot * AMPS_RECC_CAPTURE_SYMS;
-            for (int i = lane; i < AMPS_RECC_CAPTURE_SYMS; i += 64) dst[i] = s.sym[i];
-        }
-        if (slot < a.rec_cap) decode_burst_wave(s, c, nc, a.records + slot, a.majority != 0);
-        else { if (lane == 0) { atomicOr(a.status, 4u); __threadfence(); } }   // rare: performed before this workgroup counts itself done
-        __syncthreads();
-    }
-    // the workgroup that finishes last publishes the list's running {count, status} to host memory: drain_begin needs no
-    // device-to-host copy on the stream (4.4 us of it per push in the pipelined flow).  Only the workgroups that had a capture
-    // (and workgroup 0) take part.  No fence here: a fence would wait for this workgroup's record stores to cross PCIe (measured:
-    // +30 us per launch); the header needs only the two device-side counters, and the slot counter's atomic has returned
-    // its value to this wave before the one below is issued.
-    const uint32_t nb = ncap < gridDim.x ? (ncap ? ncap : 1u) : gridDim.x;
-    if (lane == 0 && blockIdx.x < nb) {
+    if (tid == 0) {
+        a.next_allowed[c] = next_allowed; a.pending[c] = pend;
+        // the workgroup that finishes last publishes the list's running {count, status} to host memory: drain_begin needs no
+        // device-to-host copy on the stream (4.4 us of it per push in the pipelined flow).  No fence here: a fence would wait for
+        // this workgroup's record stores to cross PCIe (measured: +30 us per launch); the header needs only the two device-side
+        // counters, and every slot atomic of this workgroup has returned its value (the barrier in flush) before the one below.
         const uint32_t t = atomicAdd(a.done_blocks, 1u);
-        if (t == nb - 1) {
+        if (t == gridDim.x - 1) {
             a.hdr_host[0] = atomicAdd(a.nrecords, 0u);
             a.hdr_host[1] = atomicOr(a.status, 0u);
             atomicExch(a.done_blocks, 0u);

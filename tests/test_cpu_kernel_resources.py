@@ -45,9 +45,9 @@ def test_small_kernels_fit_many_per_cu(res):
     for name, r in _one(res, "void amps::recc_bits_kernel<3, false>").items():
         assert r["vgprs"] <= 64 and r["lds_bytes"] <= 4096 and r["scratch_bytes_per_lane"] == 0, (name, r)
     for name, r in _one(res, "void amps::recc_resolve_kernel<256, 512>").items():
-        assert r["vgprs"] <= 64 and r["lds_bytes"] <= 16 * 1024, (name, r)
-    for name, r in _one(res, "amps::recc_capture_kernel").items():
-        assert r["lds_bytes"] <= 16 * 1024 and r["vgprs"] <= 168, (name, r)   # 12 bursts in flight per CU
+        # resolve + capture + decode, one workgroup per channel: four of them per CU (832 channels on 256 CUs in one round);
+        # static LDS + at most 28 KB of dynamic decode scratch (sps 10) stays under 40 KB
+        assert r["vgprs"] <= 128 and r["waves_per_simd"] >= 4 and r["lds_bytes"] <= 12 * 1024, (name, r)
 
 
 def test_no_kernel_spills_into_the_hot_path_unnoticed(res):
