@@ -216,7 +216,7 @@ int reset_state(amps_recc *h)
         HIP_TRY(hipMemsetAsync(h->detcount, 0, sizeof(uint32_t) * (size_t)h->C * h->max_chunks, s));
         HIP_TRY(hipMemsetAsync(h->next_allowed, 0, sizeof(uint64_t) * h->C, s));
         HIP_TRY(hipMemsetAsync(h->pending, 0xff, sizeof(uint64_t) * h->C, s));
-        HIP_TRY(hipMemsetAsync(h->done_blocks, 0, sizeof(uint32_t), s));
+        HIP_TRY(hipMemsetAsync(h->done_blocks, 0, (1 + DONE_GROUPS) * sizeof(uint32_t), s));
     }
     for (int b = 0; b < 2; b++) {
         HIP_TRY(hipMemsetAsync(h->nrecords_buf[b], 0, 2 * sizeof(uint32_t), s));
@@ -373,10 +373,22 @@ static void launch_resolve(amps_recc *h, ResolveArgs &ra, hipStream_t s)
     ra.burst_syms = h->bsym_dev_buf[h->cur_buf];
     ra.done_blocks = h->done_blocks; ra.hdr_host = h->hdr_dev + HDR_STRIDE * h->cur_buf;
     const size_t lds = resolve_dyn_lds(h->sps);
+#ifdef RESOLVE_TIMELINE
+    static unsigned long long *tl_dev = nullptr;
+    if (!tl_dev) (void)hipMalloc((void **)&tl_dev, (size_t)24 * 8 * 4096);
+    if (tl_dev && h->C <= 4096) { (void)hipMemsetAsync(tl_dev, 0, (size_t)24 * 8 * h->C, s); ra.tl = tl_dev; }
+#endif
     if (ra.tiles_per_channel / ra.span + 2 > (uint64_t)RESOLVE_THREADS)
         hipLaunchKernelGGL((recc_resolve_kernel<RESOLVE_THREADS_WIDE, RESOLVE_LDS_HITS_WIDE>), dim3(h->C), dim3(RESOLVE_THREADS_WIDE), lds, s, ra);
     else
         hipLaunchKernelGGL((recc_resolve_kernel<RESOLVE_THREADS, RESOLVE_LDS_HITS>), dim3(h->C), dim3(RESOLVE_THREADS), lds, s, ra);
+#ifdef RESOLVE_TIMELINE
+    if (const char *path = std::getenv("AMPS_RECC_RESOLVE_TIMELINE")) {   // the last launch's stamps, raw
+        std::vector<unsigned long long> tl((size_t)24 * h->C);
+        if (ra.tl && hipStreamSynchronize(s) == hipSuccess && hipMemcpy(tl.data(), ra.tl, tl.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
+            if (FILE *f = std::fopen(path, "wb")) { std::fwrite(tl.data(), 8, tl.size(), f); std::fclose(f); }
+    }
+#endif
 }
 
 int run_iq_device(amps_recc *h, const float2 *iq, uint64_t ld, uint32_t nsamp)
@@ -566,7 +578,7 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
         rc |= dev_alloc(&h->detcount, C * h->max_chunks);
         rc |= dev_alloc(&h->next_allowed, C);
         rc |= dev_alloc(&h->pending, C);
-        rc |= dev_alloc(&h->done_blocks, 1);
+        rc |= dev_alloc(&h->done_blocks, 1 + DONE_GROUPS);
     }
     if (!rc && cfg->wideband_channels) rc = channelizer_create(h->chz, *cfg, h->stream);
     if (!rc) rc = reset_state(h);

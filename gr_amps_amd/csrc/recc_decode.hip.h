@@ -295,6 +295,12 @@ __device__ __forceinline__ void manchester_from_ring(DecodeCore &s, const uint64
 }
 
 // BCH + first-valid-repeat + field parse + record write of the burst whose Manchester bits are in s.bits; all 64 lanes of ONE wave.
+// coalesced copy of the staged record to HBM
+__device__ __forceinline__ void decode_core_store(const DecodeCore &s, amps_recc_burst_t *__restrict__ out, int lane)
+{
+    for (int i = lane; i < (int)(sizeof(amps_recc_burst_t) / 4); i += 64) ((uint32_t *)out)[i] = ((const uint32_t *)&s.rec)[i];
+}
+
 // Tl: optional stage stamps (scripts/ubench_decode.hip); NoTl compiles to nothing.
 struct NoTl { __device__ __forceinline__ void mark(int) {} };
 template <class Sync, class Tl = NoTl>
@@ -459,8 +465,7 @@ __device__ __forceinline__ void decode_core_wave(DecodeCore &s, uint32_t channel
     }
     Sync::sync();
     tl.mark(6);
-    // coalesced copy of the staged record to HBM
-    for (int i = lane; i < (int)(sizeof(amps_recc_burst_t) / 4); i += 64) ((uint32_t *)out)[i] = ((const uint32_t *)&s.rec)[i];
+    if (out) decode_core_store(s, out, lane);
     tl.mark(7);
 }
 

@@ -38,9 +38,15 @@ struct ResolveArgs {
     uint32_t rec_cap;
     uint32_t majority;         // decode mode (AMPS_RECC_FLAG_MAJORITY)
     uint8_t *burst_syms;       // optional [rec_cap][3374]: the captured symbols of record `slot` (AMPS_RECC_FLAG_KEEP_BURSTS)
-    uint32_t *done_blocks;     // workgroups of this launch that have finished (the last one publishes the header and clears it)
+    uint32_t *done_blocks;     // [1 + DONE_GROUPS] workgroups of this launch that have finished (the last one publishes the header; see DONE_GROUPS)
     uint32_t *hdr_host;        // mapped pinned {nrecords, status} of the record list: what a drain reads, no copy on the stream
+    unsigned long long *tl;    // -DRESOLVE_TIMELINE builds: [C][24] s_memtime stamps of every workgroup's thread 0 (scripts/resolve_timeline.py)
 };
+#ifdef RESOLVE_TIMELINE
+#define RTL(k) do { if (a.tl && tid == 0) a.tl[(size_t)blockIdx.x * 24 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RTL(k) do { } while (0)
+#endif
 
 constexpr int CAP_WAVES = 4;               // waves of a workgroup that decode captures side by side
 // dynamic LDS of the kernel: per decoding wave one DecodeCore and the ring words of one capture
@@ -48,34 +54,70 @@ __host__ __device__ constexpr uint32_t resolve_cap_stride(uint32_t cap_words) { 
 inline uint32_t resolve_cap_words(uint32_t sps) { return (AMPS_RECC_CAPTURE_SYMS * sps) / 64 + 3; }
 inline size_t resolve_dyn_lds(uint32_t sps) { return (size_t)CAP_WAVES * resolve_cap_stride(resolve_cap_words(sps)) * 8; }
 
-// One accepted capture (channel c, symbol-timing position nc), by all 64 lanes of one wave.
-__device__ __forceinline__ void capture_decode_wave(const ResolveArgs &a, uint32_t c, uint64_t nc, uint64_t *scratch, int lane)
+// One accepted capture (channel c, symbol-timing position nc), by all 64 lanes of one wave: ring words -> Manchester bits ->
+// BCH -> parsed record, staged in the wave's LDS scratch (capture_store_wave writes it out once its slot is known).
+#ifdef RESOLVE_TIMELINE
+struct RtlStamps {
+    unsigned long long *dst;
+    __device__ __forceinline__ void mark(int k) { if (dst) dst[k] = __builtin_amdgcn_s_memtime(); }
+};
+#else
+typedef NoTl RtlStamps;
+#endif
+__device__ __forceinline__ void capture_gather_wave(const ResolveArgs &a, uint32_t c, uint64_t nc, uint64_t *scratch, int lane, RtlStamps tl = RtlStamps())
 {
-    DecodeCore &k = *(DecodeCore *)scratch;
     uint64_t *s_ring = scratch + (sizeof(DecodeCore) + 7) / 8;
     const uint64_t *ring = a.gring + (uint64_t)c * a.ring_words;
     const uint64_t w0 = (nc + a.sps) >> 6;
     const int nw = (int)(((nc + (uint64_t)a.sps * AMPS_RECC_CAPTURE_SYMS) >> 6) - w0) + 1;
-    for (int i = lane; i < nw; i += 64) s_ring[i] = ring[(w0 + (uint64_t)i) & a.ring_mask];
-    uint32_t slot = 0;
-    if (lane == 0) slot = atomicAdd(a.nrecords, 1u);
-    slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
-    if (slot >= a.rec_cap) {
-        if (lane == 0) { atomicOr(a.status, 4u); __threadfence(); }   // rare: performed before this workgroup counts itself done
-        return;
+    // eight loads in flight per lane: the plain loop waited out one HBM round trip per 64 words (three for sps 3: 9 of the 20 us
+    // a workgroup with a burst lived)
+    for (int i0 = 0; i0 < nw; i0 += 512) {
+        uint64_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + 64 * u + lane;
+            v[u] = i < nw ? ring[(w0 + (uint64_t)i) & a.ring_mask] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + 64 * u + lane;
+            if (i < nw) s_ring[i] = v[u];
+        }
     }
     WaveSync::sync();
+    tl.mark(8);
+}
+__device__ __forceinline__ void capture_decode_wave(const ResolveArgs &a, uint32_t c, uint64_t nc, uint64_t *scratch, int lane, RtlStamps tl = RtlStamps())
+{
+    DecodeCore &k = *(DecodeCore *)scratch;
+    const uint64_t *s_ring = scratch + (sizeof(DecodeCore) + 7) / 8;
+    const uint64_t w0 = (nc + a.sps) >> 6;
+    manchester_from_ring<WaveSync>(k, s_ring, nc, w0, a.sps, lane);
+    tl.mark(0);
+    decode_core_wave<WaveSync>(k, c, nc, nullptr, a.majority != 0, lane, tl);
+}
+__device__ __forceinline__ void capture_store_wave(const ResolveArgs &a, uint64_t nc, uint32_t slot, const uint64_t *scratch, int lane)
+{
+    const DecodeCore &k = *(const DecodeCore *)scratch;
+    decode_core_store(k, a.records + slot, lane);
     if (a.burst_syms) {
+        const uint64_t *s_ring = scratch + (sizeof(DecodeCore) + 7) / 8;
+        const uint64_t w0 = (nc + a.sps) >> 6;
         uint8_t *dst = a.burst_syms + (uint64_t)slot * AMPS_RECC_CAPTURE_SYMS;
         for (int i = lane; i < AMPS_RECC_CAPTURE_SYMS; i += 64) {
             const uint64_t n = nc + (uint64_t)a.sps * (uint64_t)(i + 1);
             dst[i] = (uint8_t)((s_ring[(n >> 6) - w0] >> (n & 63)) & 1ull);
         }
     }
-    manchester_from_ring<WaveSync>(k, s_ring, nc, w0, a.sps, lane);
-    decode_core_wave<WaveSync>(k, c, nc, a.records + slot, a.majority != 0, lane);
-    WaveSync::sync();
 }
+
+// Same-address device-scope atomics are performed at the memory side of the eight XCDs' L2s, one every ~20 ns (measured: 832
+// workgroups counting themselves done on ONE counter cost 17 us per launch, and one slot atomic per burst another 20 ns per
+// burst).  So the workgroups count themselves done on DONE_GROUPS group counters (channel mod DONE_GROUPS) and only the last of
+// a group steps the top counter; and a workgroup reserves the record slots of a whole batch of captures with one atomic,
+// issued before the decode and consumed after it.
+constexpr uint32_t DONE_GROUPS = 32;       // done_blocks[0] = top counter, [1 + g] = group g
 
 constexpr int RESOLVE_THREADS = 256;       // many channels, few segments each
 constexpr int RESOLVE_THREADS_WIDE = 1024; // few channels, thousands of segments each (one channel x 2^26 samples)
@@ -96,24 +138,51 @@ __global__ __launch_bounds__(THREADS, 4) void recc_resolve_kernel(ResolveArgs a)
     __shared__ uint64_t s_acc[HITS + 1];                           // +1: the pending capture of an earlier push
     __shared__ uint8_t  s_head[HITS], s_accf[HITS];
     __shared__ uint64_t s_na_out, s_pend;
-    __shared__ uint32_t s_total, s_nacc;
+    __shared__ uint32_t s_total, s_nacc, s_base;
     extern __shared__ uint64_t s_cap[];                            // [CAP_WAVES][resolve_cap_stride]
     const int c = blockIdx.x, tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    RTL(0);
     const uint64_t span_hold = (uint64_t)a.sps * (AMPS_RECC_CAPTURE_SYMS + AMPS_RECC_TRIGGER_SYMS);
     const uint64_t span_done = (uint64_t)a.sps * (AMPS_RECC_CAPTURE_SYMS + 1);
     uint64_t next_allowed = a.next_allowed[c];                        // uniform across the block
     uint64_t pend = a.pending[c];
     auto centre = [](uint64_t ei) -> uint64_t { return (ei >> 8) + (uint32_t)(ei & 0xff) / 2; };   // of the run of matching phases
 
-    // accepted captures are collected in LDS; the first CAP_WAVES waves then capture and decode them, one each in turn
+    // accepted captures are collected in LDS; the first CAP_WAVES waves then capture and decode them, one each per round.  The
+    // slots of the whole batch are reserved by the last wave with one atomic whose round trip hides behind the first decode.
     auto flush = [&]() {                                              // all threads
         __syncthreads();
         const uint32_t m = s_nacc;
-        if (wv < CAP_WAVES)
-            for (uint32_t i = (uint32_t)wv; i < m; i += CAP_WAVES)
-                capture_decode_wave(a, (uint32_t)c, s_acc[i], s_cap + (size_t)wv * resolve_cap_stride(a.cap_words), lane);
-        __syncthreads();
+        if (m) {
+            for (uint32_t i0 = 0; i0 < m; i0 += CAP_WAVES) {
+                const uint32_t i = i0 + (uint32_t)wv;
+                const bool mine = wv < CAP_WAVES && i < m;
+                uint64_t *scr = s_cap + (size_t)wv * resolve_cap_stride(a.cap_words);
+#ifdef RESOLVE_TIMELINE
+                RtlStamps st{ (a.tl && tid == 0) ? a.tl + (size_t)blockIdx.x * 24 + 8 : nullptr };
+#else
+                RtlStamps st;
+#endif
+                if (mine) capture_gather_wave(a, (uint32_t)c, s_acc[i], scr, lane, st);
+                if (i0 == 0) {
+                    // the slot atomic goes out BEHIND the ring loads: vector memory returns in order per CU, and this one queues at
+                    // the memory side behind every other workgroup's (measured: issued first, it held the ring words back 7 us)
+                    __syncthreads();
+                    if (tid == THREADS - 1) s_base = atomicAdd(a.nrecords, m);
+                }
+                if (mine) capture_decode_wave(a, (uint32_t)c, s_acc[i], scr, lane, st);
+                RTL(3);
+                __syncthreads();
+                RTL(4);
+                if (mine) {
+                    const uint32_t slot = s_base + i;
+                    if (slot < a.rec_cap) capture_store_wave(a, s_acc[i], slot, scr, lane);
+                    else if (lane == 0) { atomicOr(a.status, 4u); __threadfence(); }   // rare: performed before this workgroup counts itself done
+                }
+                __syncthreads();
+            }
+        }
     };
     if (tid == 0) s_nacc = 0;
     if (pend != ~0ull && pend + span_done < a.n_proc) {
@@ -146,6 +215,7 @@ __global__ __launch_bounds__(THREADS, 4) void recc_resolve_kernel(ResolveArgs a)
         if (tid == THREADS - 1) s_total = incl;
         __syncthreads();
         const uint32_t batch_total = s_total;
+        RTL(1);
         const uint64_t *d = det + (uint64_t)ch * a.det_cap;
         for (uint32_t win = 0; win == 0 || win < batch_total; win += HITS) {
             if (tid == 0) { s_pend = ~0ull; s_na_out = next_allowed; }
@@ -189,7 +259,9 @@ __global__ __launch_bounds__(THREADS, 4) void recc_resolve_kernel(ResolveArgs a)
             __syncthreads();
             next_allowed = s_na_out;
             if (s_pend != ~0ull) pend = s_pend;
+            RTL(2);
             flush();
+            RTL(5);
             if (tid == 0) s_nacc = 0;
             __syncthreads();
         }
@@ -200,12 +272,19 @@ __global__ __launch_bounds__(THREADS, 4) void recc_resolve_kernel(ResolveArgs a)
         // device-to-host copy on the stream (4.4 us of it per push in the pipelined flow).  No fence here: a fence would wait for
         // this workgroup's record stores to cross PCIe (measured: +30 us per launch); the header needs only the two device-side
         // counters, and every slot atomic of this workgroup has returned its value (the barrier in flush) before the one below.
-        const uint32_t t = atomicAdd(a.done_blocks, 1u);
-        if (t == gridDim.x - 1) {
-            a.hdr_host[0] = atomicAdd(a.nrecords, 0u);
-            a.hdr_host[1] = atomicOr(a.status, 0u);
-            atomicExch(a.done_blocks, 0u);
+        RTL(6);
+        const uint32_t ng = gridDim.x < DONE_GROUPS ? gridDim.x : DONE_GROUPS;
+        const uint32_t g = blockIdx.x % DONE_GROUPS;
+        const uint32_t gsize = (gridDim.x - g + DONE_GROUPS - 1) / DONE_GROUPS;
+        if (atomicAdd(a.done_blocks + 1 + g, 1u) == gsize - 1) {
+            atomicExch(a.done_blocks + 1 + g, 0u);
+            if (atomicAdd(a.done_blocks, 1u) == ng - 1) {
+                a.hdr_host[0] = atomicAdd(a.nrecords, 0u);
+                a.hdr_host[1] = atomicOr(a.status, 0u);
+                atomicExch(a.done_blocks, 0u);
+            }
         }
+        RTL(7);
     }
 }
 
