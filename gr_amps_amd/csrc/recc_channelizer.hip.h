@@ -81,6 +81,9 @@ struct ChzArgs {
     uint32_t ring_words;
     uint64_t n_done;         // absolute channel-stream sample index of frame 0 (multiple of 64)
     uint32_t stream_start;   // frame 0 of this launch is the first frame of the stream (spec B: its first 3 bits are ones)
+    // the carry of the NEXT launch, written by this one (every workgroup copies a slice; the two carry buffers alternate)
+    float2 *carry_out;       // [carry_out_len]: virtual samples [consumed - hist, consumed - hist + carry_out_len)
+    uint32_t consumed, carry_out_len;
     unsigned long long *tl;  // CHZ_TIMELINE builds: s_memtime stamps of workgroup 0 ([wave][step][8]), else unused
 };
 constexpr int CHZ_PRE = 4;   // frames of history the carry keeps beyond the filter's own L - D samples: what the exact half of a workgroup's pre-roll reaches back to
@@ -643,6 +646,29 @@ constexpr int CHZ_TL_FIRST = 40;
 #define CHZ_TL_FLUSH do { } while (0)
 #endif
 
+// carry_out[k] = virtual sample (consumed - hist + k), k in [0, hist + leftover_new)
+__device__ __forceinline__ float2 chz_carry_sample(const float2 *block, const float2 *carry_in, uint32_t carry_len, uint32_t nsamp,
+                                                   uint32_t hist, uint32_t consumed, uint32_t k)
+{
+    const int64_t lead = (int64_t)carry_len - hist;
+    const int64_t v = (int64_t)consumed - hist + k;   // launch-relative virtual index
+    const int64_t ci = v + hist;
+    float2 s = make_float2(0.f, 0.f);
+    if (ci >= 0) {
+        if (ci < (int64_t)carry_len) s = carry_in[ci];
+        else { const int64_t bi = v - lead; if (bi < (int64_t)nsamp) s = block[bi]; }
+    }
+    return s;
+}
+// stand-alone form: a push too short to produce a frame only moves the carry
+__global__ __launch_bounds__(256) void chz_carry_kernel(const float2 *block, const float2 *carry_in, float2 *carry_out,
+                                                         uint32_t carry_len, uint32_t nsamp, uint32_t hist, uint32_t consumed,
+                                                         uint32_t out_len)
+{
+    for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < out_len; k += gridDim.x * 256)
+        carry_out[k] = chz_carry_sample(block, carry_in, carry_len, nsamp, hist, consumed, k);
+}
+
 template <int P, int MODE>
 __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
 {
@@ -671,6 +697,16 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
     const bool p3_on = p3_v < 4u * a.grp_w;
     const int p3_f = (int)(p3_v / a.grp_w) & 3, p3_i = (int)(a.grp_r * a.grp_w + p3_v % a.grp_w);
     if (role == 2) __builtin_amdgcn_s_setprio(2); else if (role == 1) __builtin_amdgcn_s_setprio(1);   // (six other priority triples measured: all within the run-to-run noise of this one)
+    // The next launch's carry (the last L - D + 4 D samples and the leftover) is a ~80 KB copy: every workgroup moves its slice
+    // here, a sample per thread of wave 0, instead of a kernel of its own behind this one (4.4 us + a launch gap per push).  Not
+    // in the fold waves: their vmcnt windows count their own loads only.
+    if (a.carry_out && wave == 0) {
+        const uint32_t per = (a.carry_out_len + gridDim.x - 1) / gridDim.x;
+        const uint32_t k0 = blockIdx.x * per;
+        const uint32_t k1 = k0 + per < a.carry_out_len ? k0 + per : a.carry_out_len;
+        for (uint32_t k = k0 + (uint32_t)lane; k < k1; k += 64)
+            a.carry_out[k] = chz_carry_sample(a.block, a.carry, a.carry_len, a.nsamp, a.hist, a.consumed, k);
+    }
     const int64_t f0 = (int64_t)blockIdx.x * a.frames_per_wg;   // multiple of 64
     if (f0 >= (int64_t)a.nframes) return;
     int64_t f1 = f0 + a.frames_per_wg; if (f1 > (int64_t)a.nframes) f1 = a.nframes;
@@ -818,24 +854,6 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
             }
         }
         CHZ_TL_FLUSH;
-    }
-}
-
-// carry_out[k] = virtual sample (consumed - hist + k), k in [0, hist + leftover_new)
-__global__ __launch_bounds__(256) void chz_carry_kernel(const float2 *block, const float2 *carry_in, float2 *carry_out,
-                                                         uint32_t carry_len, uint32_t nsamp, uint32_t hist, uint32_t consumed,
-                                                         uint32_t out_len)
-{
-    const int64_t lead = (int64_t)carry_len - hist;
-    for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < out_len; k += gridDim.x * 256) {
-        int64_t v = (int64_t)consumed - hist + k;   // launch-relative virtual index
-        int64_t ci = v + hist;
-        float2 s = make_float2(0.f, 0.f);
-        if (ci >= 0) {
-            if (ci < (int64_t)carry_len) s = carry_in[ci];
-            else { int64_t bi = v - lead; if (bi < (int64_t)nsamp) s = block[bi]; }
-        }
-        carry_out[k] = s;
     }
 }
 
@@ -1002,6 +1020,9 @@ inline int channelizer_run(ChannelizerState &z, const float2 *iq, size_t nsamp, 
 #ifdef CHZ_TIMELINE
     unsigned long long *a_tl_last = nullptr;
 #endif
+    const uint32_t consumed = nframes * CHZ_D;                        // virtual samples consumed (incl. leftover)
+    const uint32_t new_left = (uint32_t)(avail - consumed);
+    bool carry_in_kernel = false;
     if (nframes) {
         ChzArgs a{};
         a.block = d; a.carry = z.carry[z.carry_cur]; a.taps = z.taps; a.out = z.out; a.ld = z.ld;
@@ -1016,6 +1037,8 @@ inline int channelizer_run(ChannelizerState &z, const float2 *iq, size_t nsamp, 
         a.gring = gring; a.ring_words = ring_words; a.n_done = n_done;
         a.stream_start = z.frames_done == 0 ? 1u : 0u;
         const dim3 g12((nframes + fpw - 1) / fpw), b12(768);
+        carry_in_kernel = g12.x >= 64;                                // a slice of at most ~700 samples per workgroup; smaller grids leave it to the copy kernel
+        if (carry_in_kernel) { a.carry_out = z.carry[z.carry_cur ^ 1]; a.consumed = consumed; a.carry_out_len = hist + new_left; }
 #ifdef CHZ_TIMELINE
         static unsigned long long *tl_dev = nullptr;
         constexpr size_t TLN = 12 * 8;
@@ -1037,10 +1060,9 @@ inline int channelizer_run(ChannelizerState &z, const float2 *iq, size_t nsamp, 
             if (FILE *f = std::fopen(path, "wb")) { std::fwrite(tl.data(), 8, tl.size(), f); std::fclose(f); }
     }
 #endif
-    const uint32_t consumed = nframes * CHZ_D;                        // virtual samples consumed (incl. leftover)
-    const uint32_t new_left = (uint32_t)(avail - consumed);
-    hipLaunchKernelGGL(chz_carry_kernel, dim3((hist + new_left + 255) / 256), dim3(256), 0, s, d, z.carry[z.carry_cur],
-                       z.carry[z.carry_cur ^ 1], z.carry_len, (uint32_t)nsamp, hist, consumed, hist + new_left);
+    if (!carry_in_kernel)
+        hipLaunchKernelGGL(chz_carry_kernel, dim3((hist + new_left + 255) / 256), dim3(256), 0, s, d, z.carry[z.carry_cur],
+                           z.carry[z.carry_cur ^ 1], z.carry_len, (uint32_t)nsamp, hist, consumed, hist + new_left);
     if (hipGetLastError() != hipSuccess) return -EIO;
     if (mem == AMPS_MEM_HOST) { if (int rc = z.stage_fence.arm(s)) return rc; }
     z.carry_cur ^= 1;
