@@ -771,6 +771,13 @@ int run_bits_device(amps_recc *h, uint32_t P)
         } else if (fa.tol) hipLaunchKernelGGL((recc_bits_kernel<3, true>), grid, dim3(256), 0, s, fa);
         else hipLaunchKernelGGL((recc_bits_kernel<3, false>), grid, dim3(256), 0, s, fa);
     }
+#ifdef BITS_TIMELINE
+    if (const char *path = std::getenv("AMPS_RECC_BITS_TIMELINE")) {
+        std::vector<unsigned long long> tl(3 * 16384);
+        if (hipStreamSynchronize(s) == hipSuccess && hipMemcpyFromSymbol(tl.data(), HIP_SYMBOL(bits_tl), tl.size() * 8) == hipSuccess)
+            if (FILE *f = std::fopen(path, "wb")) { unsigned long long nw = nwaves; std::fwrite(&nw, 8, 1, f); std::fwrite(tl.data(), 8, tl.size(), f); std::fclose(f); }
+    }
+#endif
     ResolveArgs ra{};
     ra.det = h->det; ra.detcount = h->detcount; ra.max_chunks = h->max_chunks; ra.det_cap = h->det_cap;
     ra.tiles_per_channel = Tc; ra.span = span; ra.sps = h->sps; ra.n_proc = h->n_done + P;

@@ -30,7 +30,7 @@ def run(r, push, label):
 
 # channel-major IQ seam, 832 x 2^18 @ sps 10
 C, N = 832, 1 << 18
-for nb in (0, 1, 2):
+for nb in (() if "wide" in sys.argv[1:] else (0, 1, 2)):
     xs = [synth.make_channel_block(N, nb, seed=1000 + c, sps=10)[0] for c in range(16)]
     d = torch.from_numpy(np.stack(xs)).to(dev).repeat(52, 1)[:C].contiguous()
     with capi.Recc(n_channels=C, sps=10, max_samples=N, max_bursts=8192, time_kernels=True, sync_torch=False) as r:
