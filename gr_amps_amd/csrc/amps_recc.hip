@@ -66,6 +66,8 @@ struct amps_recc {
     uint32_t *detcount = nullptr;
     uint64_t *next_allowed = nullptr, *pending = nullptr;
     uint32_t *done_blocks = nullptr;              // resolve workgroups of the launch in flight that have finished
+    uint64_t *capq = nullptr;                     // queue form of the capture (few channels: resolve_uses_queue)
+    uint32_t *capq_count = nullptr;
     amps_recc_burst_t *records = nullptr;
     uint32_t *nrecords = nullptr;
     uint32_t *status = nullptr;
@@ -217,6 +219,7 @@ int reset_state(amps_recc *h)
         HIP_TRY(hipMemsetAsync(h->next_allowed, 0, sizeof(uint64_t) * h->C, s));
         HIP_TRY(hipMemsetAsync(h->pending, 0xff, sizeof(uint64_t) * h->C, s));
         HIP_TRY(hipMemsetAsync(h->done_blocks, 0, (1 + DONE_GROUPS) * sizeof(uint32_t), s));
+        if (h->capq_count) HIP_TRY(hipMemsetAsync(h->capq_count, 0, sizeof(uint32_t), s));
     }
     for (int b = 0; b < 2; b++) {
         HIP_TRY(hipMemsetAsync(h->nrecords_buf[b], 0, 2 * sizeof(uint32_t), s));
@@ -355,7 +358,7 @@ int dispatch_front(uint32_t sps, const FrontArgs &fa, dim3 grid, hipStream_t s, 
 void front_housekeeping_args(amps_recc *h, FrontArgs &fa)
 {
     h->open_untouched = false;              // this launch may clear the counters of the list a split drain has open
-    fa.zero1 = nullptr;
+    fa.zero1 = h->capq_count;               // null in the fused form
     const int idle = h->cur_buf ^ 1;
     fa.zero2 = h->list_clean[idle] ? nullptr : h->nrecords_buf[idle];
     h->list_clean[idle] = true;
@@ -372,7 +375,8 @@ static void launch_resolve(amps_recc *h, ResolveArgs &ra, hipStream_t s)
     ra.majority = (h->cfg.flags & AMPS_RECC_FLAG_MAJORITY) ? 1u : 0u;
     ra.burst_syms = h->bsym_dev_buf[h->cur_buf];
     ra.done_blocks = h->done_blocks; ra.hdr_host = h->hdr_dev + HDR_STRIDE * h->cur_buf;
-    const size_t lds = resolve_dyn_lds(h->sps);
+    ra.capq = h->capq; ra.capq_count = h->capq_count; ra.capq_cap = h->cfg.max_bursts;
+    const size_t lds = h->capq ? 0 : resolve_dyn_lds(h->sps);
 #ifdef RESOLVE_TIMELINE
     static unsigned long long *tl_dev = nullptr;
     if (!tl_dev) (void)hipMalloc((void **)&tl_dev, (size_t)24 * 8 * 4096);
@@ -382,6 +386,9 @@ static void launch_resolve(amps_recc *h, ResolveArgs &ra, hipStream_t s)
         hipLaunchKernelGGL((recc_resolve_kernel<RESOLVE_THREADS_WIDE, RESOLVE_LDS_HITS_WIDE>), dim3(h->C), dim3(RESOLVE_THREADS_WIDE), lds, s, ra);
     else
         hipLaunchKernelGGL((recc_resolve_kernel<RESOLVE_THREADS, RESOLVE_LDS_HITS>), dim3(h->C), dim3(RESOLVE_THREADS), lds, s, ra);
+    if (h->capq)
+        hipLaunchKernelGGL(recc_capture_kernel, dim3(std::min<uint32_t>(h->cfg.max_bursts, 2048u)), dim3(64),
+                           (size_t)resolve_cap_stride(ra.cap_words) * 8, s, ra);
 #ifdef RESOLVE_TIMELINE
     if (const char *path = std::getenv("AMPS_RECC_RESOLVE_TIMELINE")) {   // the last launch's stamps, raw
         std::vector<unsigned long long> tl((size_t)24 * h->C);
@@ -579,6 +586,7 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
         rc |= dev_alloc(&h->next_allowed, C);
         rc |= dev_alloc(&h->pending, C);
         rc |= dev_alloc(&h->done_blocks, 1 + DONE_GROUPS);
+        if (resolve_uses_queue((uint32_t)C)) { rc |= dev_alloc(&h->capq, cfg->max_bursts); rc |= dev_alloc(&h->capq_count, 1); }
     }
     if (!rc && cfg->wideband_channels) rc = channelizer_create(h->chz, *cfg, h->stream);
     if (!rc) rc = reset_state(h);
@@ -597,7 +605,7 @@ void amps_recc_destroy(amps_recc_t *h)
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
     h->event_pool.clear();
     void *bufs[] = { h->carry[0], h->carry[1], h->gring, h->det, h->detcount, h->next_allowed, h->pending,
-                     h->done_blocks, h->nrecords_buf[0], h->nrecords_buf[1], h->stage_iq, h->symbuf, h->sym_len, h->sym_cur,
+                     h->done_blocks, h->capq, h->capq_count, h->nrecords_buf[0], h->nrecords_buf[1], h->stage_iq, h->symbuf, h->sym_len, h->sym_cur,
                      h->sym_stage, h->bursts_dev, h->burst_chan_dev, h->nbursts_dev, h->dec_out_dev, h->dec_in_dev,
                      h->dec_chan_dev, h->dbg_d, h->dbg_S, h->bch_in, h->bch_out, h->bch_val, h->bch_err };
     for (void *p : bufs) if (p) (void)hipFree(p);

@@ -16,7 +16,7 @@
 
 namespace amps {
 
-// the host sorts records by one packed key (channel, position): 2^44 samples per channel stream (2.8 years at 200 ksps), 2^20 channels
+// one packed key (channel, position) for the capture queue and the host's sort: 2^44 samples per channel stream (2.8 years at 200 ksps), 2^20 channels
 constexpr int CAPQ_POS_BITS = 44;
 
 struct ResolveArgs {
@@ -40,6 +40,10 @@ struct ResolveArgs {
     uint8_t *burst_syms;       // optional [rec_cap][3374]: the captured symbols of record `slot` (AMPS_RECC_FLAG_KEEP_BURSTS)
     uint32_t *done_blocks;     // [1 + DONE_GROUPS] workgroups of this launch that have finished (the last one publishes the header; see DONE_GROUPS)
     uint32_t *hdr_host;        // mapped pinned {nrecords, status} of the record list: what a drain reads, no copy on the stream
+    // queue form (few channels, see resolve_uses_queue): accepted captures go to a queue and recc_capture_kernel decodes them
+    uint64_t *capq;            // [capq_cap] (channel << CAPQ_POS_BITS | n_c), or null: decode in this kernel
+    uint32_t *capq_count;      // atomic; cleared by the streaming kernel's housekeeping
+    uint32_t capq_cap;
     unsigned long long *tl;    // -DRESOLVE_TIMELINE builds: [C][24] s_memtime stamps of every workgroup's thread 0 (scripts/resolve_timeline.py)
 };
 #ifdef RESOLVE_TIMELINE
@@ -154,7 +158,16 @@ __global__ __launch_bounds__(THREADS, 4) void recc_resolve_kernel(ResolveArgs a)
     auto flush = [&]() {                                              // all threads
         __syncthreads();
         const uint32_t m = s_nacc;
-        if (m) {
+        if (m && a.capq) {                                            // queue form: one atomicAdd per batch
+            if (tid == 0) s_base = atomicAdd(a.capq_count, m);
+            __syncthreads();
+            const uint32_t base = s_base;
+            for (uint32_t i = tid; i < m; i += THREADS) {
+                if (base + i < a.capq_cap) a.capq[base + i] = ((uint64_t)c << CAPQ_POS_BITS) | (s_acc[i] & ((1ull << CAPQ_POS_BITS) - 1));
+                else atomicOr(a.status, 2u);
+            }
+            __syncthreads();
+        } else if (m) {
             for (uint32_t i0 = 0; i0 < m; i0 += CAP_WAVES) {
                 const uint32_t i = i0 + (uint32_t)wv;
                 const bool mine = wv < CAP_WAVES && i < m;
@@ -266,8 +279,8 @@ __global__ __launch_bounds__(THREADS, 4) void recc_resolve_kernel(ResolveArgs a)
             __syncthreads();
         }
     }
-    if (tid == 0) {
-        a.next_allowed[c] = next_allowed; a.pending[c] = pend;
+    if (tid == 0) { a.next_allowed[c] = next_allowed; a.pending[c] = pend; }
+    if (tid == 0 && !a.capq) {
         // the workgroup that finishes last publishes the list's running {count, status} to host memory: drain_begin needs no
         // device-to-host copy on the stream (4.4 us of it per push in the pipelined flow).  No fence here: a fence would wait for
         // this workgroup's record stores to cross PCIe (measured: +30 us per launch); the header needs only the two device-side
@@ -285,6 +298,42 @@ __global__ __launch_bounds__(THREADS, 4) void recc_resolve_kernel(ResolveArgs a)
             }
         }
         RTL(7);
+    }
+}
+
+// Queue form of capture + decode: one single-wave workgroup per queued capture.  Used when the handle has few channels: one
+// channel x 2^26 samples holds 745 bursts, which the resolve kernel's one workgroup would decode four at a time (1.5 ms; here
+// 0.03).  With many channels the fused form wins: no queue, no second launch, no 2048 workgroups to dispatch.
+inline bool resolve_uses_queue(uint32_t n_channels) { return n_channels < 64; }
+__global__ __launch_bounds__(64) void recc_capture_kernel(ResolveArgs a)
+{
+    extern __shared__ uint64_t s_cap[];                            // one resolve_cap_stride
+    const int lane = threadIdx.x;
+    uint32_t ncap = *a.capq_count;
+    if (ncap > a.capq_cap) ncap = a.capq_cap;
+    for (uint32_t q = blockIdx.x; q < ncap; q += gridDim.x) {
+        const uint64_t e = a.capq[q];
+        const uint32_t c = (uint32_t)(e >> CAPQ_POS_BITS);
+        const uint64_t nc = e & ((1ull << CAPQ_POS_BITS) - 1);
+        capture_gather_wave(a, c, nc, s_cap, lane);
+        uint32_t slot = 0;
+        if (lane == 0) slot = atomicAdd(a.nrecords, 1u);
+        capture_decode_wave(a, c, nc, s_cap, lane);
+        slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
+        if (slot < a.rec_cap) capture_store_wave(a, nc, slot, s_cap, lane);
+        else if (lane == 0) { atomicOr(a.status, 4u); __threadfence(); }   // rare: performed before this workgroup counts itself done
+        WaveSync::sync();
+    }
+    // the last workgroup publishes the header (see recc_resolve_kernel); only the workgroups that had a capture (and workgroup 0)
+    // take part
+    const uint32_t nb = ncap < gridDim.x ? (ncap ? ncap : 1u) : gridDim.x;
+    if (lane == 0 && blockIdx.x < nb) {
+        const uint32_t t = atomicAdd(a.done_blocks, 1u);
+        if (t == nb - 1) {
+            a.hdr_host[0] = atomicAdd(a.nrecords, 0u);
+            a.hdr_host[1] = atomicOr(a.status, 0u);
+            atomicExch(a.done_blocks, 0u);
+        }
     }
 }
 
