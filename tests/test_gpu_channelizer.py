@@ -58,6 +58,29 @@ def test_channelizer_streaming_equals_one_shot(gpu):
     assert np.array_equal(one.view(np.uint32), many.view(np.uint32))     # frame arithmetic does not depend on the chunking
 
 
+def test_channelizer_carry_written_by_the_kernel_equals_the_copy_kernel(gpu):
+    """Launches of 64 workgroups and more write the next launch's carry themselves (a slice per workgroup); shorter ones leave it to
+    chz_carry_kernel.  A stream pushed in pieces that alternate between the two forms -- with ragged leftovers in the carry --
+    comes out bit for bit as in one push (which is itself a long launch)."""
+    rng = np.random.default_rng(12)
+    pieces = [4160 * D + 13, 70 * D - 13, 4223 * D + 501, 3 * D + 11, 4100 * D - 1]   # 65 / 2 / 66 / 1 / 65 workgroups
+    n = sum(pieces)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    with _handle(64, 96, 4300) as r:
+        one = r.debug_channelize(x[:4300 * D])                 # reference for the first stretch ...
+    with _handle(64, 96, n // D + 8) as r:
+        whole = r.debug_channelize(x)                          # ... and for everything (194 workgroups)
+    assert np.array_equal(one.view(np.uint32), whole[:, :one.shape[1]].view(np.uint32))
+    with _handle(64, 96, 4300) as r:
+        parts, off = [], 0
+        for m in pieces:
+            parts.append(r.debug_channelize(x[off:off + m]))
+            off += m
+        many = np.concatenate(parts, axis=1)
+    assert many.shape == whole.shape == (64, n // D)
+    assert np.array_equal(many.view(np.uint32), whole.view(np.uint32))
+
+
 def test_wideband_bursts_decode_to_the_transmitted_words(gpu):
     first, C = 96, 832
     n = int(0.2 * sw.FS_WIDE) // D * D
