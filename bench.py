@@ -513,6 +513,9 @@ def main(argv=None):
         raise SystemExit("--gpus must equal WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the RECC path has no CPU fallback")
+    share = os.environ.get("AMPS_BENCH_SHARE_GPU") == "1"    # test knob: every rank on device 0, collectives over gloo (RCCL refuses two ranks on one
+    if share:                                                # device) -- tests/test_gpu_bench_ranks.py runs the N > 1 code on the one GPU a box has
+        local = 0
     if local >= torch.cuda.device_count():
         raise SystemExit("rank %d: only %d GPU(s) visible on this node" % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local)
@@ -522,7 +525,10 @@ def main(argv=None):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     if a.dist != "bands" and a.workload != "wideband832":
         raise SystemExit("--dist %s distributes a wideband block: use --workload wideband832" % a.dist)
 
