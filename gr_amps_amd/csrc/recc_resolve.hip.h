@@ -10,7 +10,7 @@
 //   capture   the workgroup's first CAP_WAVES waves each take accepted captures in turn: gather the 3374 slicer bits at the
 //             chosen phase from the channel's HBM bit ring, run the recc_decode core (recc_decode.hip.h), append the record.
 // (Round 2 had a capture queue and a second kernel of one workgroup per capture: 2048 workgroups to dispatch, a launch and
-// ~25 us per push for the same work.)  Latency-bound bookkeeping on kilobytes; the HBM-bound work is in recc_front.hip.h.
+// ~25 us per push for the same work.  That form is kept for handles with few channels: resolve_uses_queue.)  Latency-bound bookkeeping on kilobytes; the HBM-bound work is in recc_front.hip.h.
 #pragma once
 #include "recc_decode.hip.h"
 
@@ -28,7 +28,7 @@ struct ResolveArgs {
     uint64_t n_proc;           // absolute samples processed after this push
     uint64_t *next_allowed;    // [C]
     uint64_t *pending;         // [C], ~0 = none (holds n_c)
-    uint32_t *status;          // bit 2: record list overflow (bit 1, capture queue overflow, is no longer produced)
+    uint32_t *status;          // bit 1: capture queue overflow (queue form only), bit 2: record list overflow
     // capture + decode
     const uint64_t *gring;
     uint32_t ring_mask, ring_words;
@@ -74,8 +74,7 @@ __device__ __forceinline__ void capture_gather_wave(const ResolveArgs &a, uint32
     const uint64_t *ring = a.gring + (uint64_t)c * a.ring_words;
     const uint64_t w0 = (nc + a.sps) >> 6;
     const int nw = (int)(((nc + (uint64_t)a.sps * AMPS_RECC_CAPTURE_SYMS) >> 6) - w0) + 1;
-    // eight loads in flight per lane: the plain loop waited out one HBM round trip per 64 words (three for sps 3: 9 of the 20 us
-    // a workgroup with a burst lived)
+    // eight loads in flight per lane, not a load-wait-store loop of one round trip per 64 words (sps 10: nine of them)
     for (int i0 = 0; i0 < nw; i0 += 512) {
         uint64_t v[8];
 #pragma unroll
@@ -116,11 +115,11 @@ __device__ __forceinline__ void capture_store_wave(const ResolveArgs &a, uint64_
     }
 }
 
-// Same-address device-scope atomics are performed at the memory side of the eight XCDs' L2s, one every ~20 ns (measured: 832
-// workgroups counting themselves done on ONE counter cost 17 us per launch, and one slot atomic per burst another 20 ns per
-// burst).  So the workgroups count themselves done on DONE_GROUPS group counters (channel mod DONE_GROUPS) and only the last of
-// a group steps the top counter; and a workgroup reserves the record slots of a whole batch of captures with one atomic,
-// issued before the decode and consumed after it.
+// Same-address device-scope atomics are performed at the memory side of the eight XCDs' L2s, one every ~20 ns, and vector memory
+// returns in order per CU (measured: 832 workgroups counting themselves done on ONE counter cost 4 us per launch; a slot atomic
+// issued in front of a capture's ring loads held the ring words back 7 us).  So the workgroups count themselves done on
+// DONE_GROUPS group counters (channel mod DONE_GROUPS) and only the last of a group steps the top counter; and a workgroup reserves
+// the record slots of a whole batch of captures with one atomic, issued behind the first ring loads and consumed after the decode.
 constexpr uint32_t DONE_GROUPS = 32;       // done_blocks[0] = top counter, [1 + g] = group g
 
 constexpr int RESOLVE_THREADS = 256;       // many channels, few segments each
