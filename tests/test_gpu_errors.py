@@ -24,14 +24,24 @@ def _stream(nbursts, seed, gap_syms=3600):
     return synth.fsk_modulate(n, bursts, sps=SPS, fs=20e3 * SPS, snr_db=30.0, rng=rng)[None, :]
 
 
-def test_record_list_overflow_is_reported_and_the_handle_recovers(gpu):
+def _pad(iq, n_channels):
+    """the one real channel plus idle ones: 64 channels and more put a handle on the fused form of the capture stage (the resolve
+    kernel's own workgroup decodes), fewer on the queue form (recc_resolve.hip.h) -- the overflow paths differ"""
+    x = np.zeros((n_channels, iq.shape[1]), iq.dtype)
+    x[:1] = iq
+    return x
+
+
+@pytest.mark.parametrize("C", [1, 65])
+def test_record_list_overflow_is_reported_and_the_handle_recovers(gpu, C):
     """five bursts into a handle built for two: drain says -ENOSPC (the reference has no such limit: its message port queues),
     and the stream goes on -- the next drains are clean and complete, on both record lists"""
     iq5, iq2 = _stream(5, 1), _stream(2, 2)
     parts = [iq5, iq2, iq2, iq2]
     want = oracle.fused_push_all(np.concatenate(parts, axis=1), sps=SPS)
     assert len(want) == 11
-    with capi.Recc(n_channels=1, sps=SPS, max_samples=max(iq5.shape[1], iq2.shape[1]), max_bursts=2) as r:
+    iq5, iq2 = _pad(iq5, C), _pad(iq2, C)
+    with capi.Recc(n_channels=C, sps=SPS, max_samples=max(iq5.shape[1], iq2.shape[1]), max_bursts=2) as r:
         r.push_iq(iq5)
         with pytest.raises(capi.AmpsError) as e:
             r.drain()
@@ -43,9 +53,10 @@ def test_record_list_overflow_is_reported_and_the_handle_recovers(gpu):
             assert len(r.drain()) == 0
 
 
-def test_overflow_in_a_split_drain_does_not_leak_into_the_next_list(gpu):
-    iq5, iq2 = _stream(5, 3), _stream(2, 4)
-    with capi.Recc(n_channels=1, sps=SPS, max_samples=max(iq5.shape[1], iq2.shape[1]), max_bursts=2) as r:
+@pytest.mark.parametrize("C", [1, 65])
+def test_overflow_in_a_split_drain_does_not_leak_into_the_next_list(gpu, C):
+    iq5, iq2 = _pad(_stream(5, 3), C), _pad(_stream(2, 4), C)
+    with capi.Recc(n_channels=C, sps=SPS, max_samples=max(iq5.shape[1], iq2.shape[1]), max_bursts=2) as r:
         r.push_iq(iq5)
         r.drain_begin()
         with pytest.raises(capi.AmpsError) as e:
