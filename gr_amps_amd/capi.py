@@ -22,12 +22,14 @@ FLAG_SLICER_PRODUCT = 8
 FLAG_SLICER_SINE = 16
 FLAG_KEEP_BURSTS = 32
 FLAG_SLICER_ATAN = 64
+FLAG_SLICER_EXACT = 128
 
 # slicer names accepted by Recc(slicer=...): numeric spec of include/amps_recc_numerics.h -> cfg flag
 _SLICER_FLAGS = {None: 0, "default": 0, "atan": FLAG_SLICER_ATAN, 0: FLAG_SLICER_ATAN, "A": FLAG_SLICER_ATAN,
                  "product": FLAG_SLICER_PRODUCT, 1: FLAG_SLICER_PRODUCT, "B": FLAG_SLICER_PRODUCT,
-                 "sine": FLAG_SLICER_SINE, 2: FLAG_SLICER_SINE, "C": FLAG_SLICER_SINE}
-SLICER_NAMES = ("atan", "product", "sine")      # indexed by AMPS_SLICER_*
+                 "sine": FLAG_SLICER_SINE, 2: FLAG_SLICER_SINE, "C": FLAG_SLICER_SINE,
+                 "exact": FLAG_SLICER_EXACT, 3: FLAG_SLICER_EXACT, "D": FLAG_SLICER_EXACT}
+SLICER_NAMES = ("atan", "product", "sine", "exact")      # indexed by AMPS_SLICER_*
 
 MSG_CLASSES = ("invalid_word_a", "e_zero", "page_response", "registration", "origination", "bad_nawc", "unknown")
 
@@ -193,7 +195,7 @@ class Recc:
         if isinstance(slicer, bool) or slicer not in _SLICER_FLAGS:        # a typo must not run a different numeric spec silently
             raise ValueError("slicer must be one of %r" % sorted(map(str, _SLICER_FLAGS)))
         self.slicer = SLICER_NAMES[L.amps_recc_default_slicer() if hasattr(L, "amps_recc_default_slicer") else 0] if _SLICER_FLAGS[slicer] == 0 else \
-            {FLAG_SLICER_ATAN: "atan", FLAG_SLICER_PRODUCT: "product", FLAG_SLICER_SINE: "sine"}[_SLICER_FLAGS[slicer]]
+            {FLAG_SLICER_ATAN: "atan", FLAG_SLICER_PRODUCT: "product", FLAG_SLICER_SINE: "sine", FLAG_SLICER_EXACT: "exact"}[_SLICER_FLAGS[slicer]]
         self.sync_torch = sync_torch
         cfg = Cfg()
         cfg.struct_size = C.sizeof(Cfg)

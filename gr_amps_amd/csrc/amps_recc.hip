@@ -275,25 +275,29 @@ int front_depth(int slicer)
     if (env) return env;
     return slicer == AMPS_SLICER_ATAN_BOXCAR ? 1 : 2;
 }
+typedef void (*front_kernel_t)(FrontArgs);
+// the instantiation of the streaming kernel for (samples per symbol, slicer spec, tolerant sync, tiles in flight)
+template <int SPS, int SL> front_kernel_t front_kernel_of(bool tol, int depth)
+{
+    if (tol) return recc_front_kernel<SPS, 1, false, true, SL>;
+    if constexpr (SL == AMPS_SLICER_ATAN_BOXCAR) { if (depth == 3) return recc_front_kernel<SPS, 3, false, false, SL>; }
+    if (depth == 2) return recc_front_kernel<SPS, 2, false, false, SL>;
+    return recc_front_kernel<SPS, 1, false, false, SL>;
+}
+template <int SPS> front_kernel_t front_kernel_for(int slicer, bool tol)
+{
+    const int depth = front_depth(slicer);
+    switch (slicer) {
+    case AMPS_SLICER_PRODUCT: return front_kernel_of<SPS, AMPS_SLICER_PRODUCT>(tol, depth);
+    case AMPS_SLICER_SINE: return front_kernel_of<SPS, AMPS_SLICER_SINE>(tol, depth);
+    case AMPS_SLICER_EXACT: return front_kernel_of<SPS, AMPS_SLICER_EXACT>(tol, depth);
+    default: return front_kernel_of<SPS, AMPS_SLICER_ATAN_BOXCAR>(tol, depth);
+    }
+}
 template <int SPS> int front_blocks_per_cu(int slicer, bool tol)   // of the kernel launch_front<SPS> will pick
 {
     int n = 0;
-    hipError_t e;
-    const int depth = front_depth(slicer);
-    if (slicer == AMPS_SLICER_PRODUCT) {
-        if (tol) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, recc_front_kernel<SPS, 1, false, true, AMPS_SLICER_PRODUCT>, 256, 0);
-        else if (depth == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, recc_front_kernel<SPS, 2, false, false, AMPS_SLICER_PRODUCT>, 256, 0);
-        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, recc_front_kernel<SPS, 1, false, false, AMPS_SLICER_PRODUCT>, 256, 0);
-    } else if (slicer == AMPS_SLICER_SINE) {
-        if (tol) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, recc_front_kernel<SPS, 1, false, true, AMPS_SLICER_SINE>, 256, 0);
-        else if (depth == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, recc_front_kernel<SPS, 2, false, false, AMPS_SLICER_SINE>, 256, 0);
-        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, recc_front_kernel<SPS, 1, false, false, AMPS_SLICER_SINE>, 256, 0);
-    } else if (tol) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, recc_front_kernel<SPS, 1, false, true>, 256, 0);
-    else switch (depth) {
-    case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, recc_front_kernel<SPS, 2>, 256, 0); break;
-    case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, recc_front_kernel<SPS, 3>, 256, 0); break;
-    default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, recc_front_kernel<SPS, 1>, 256, 0); break;
-    }
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, front_kernel_for<SPS>(slicer, tol), 256, 0);
     return (e == hipSuccess && n > 0) ? n : 2;
 }
 int front_blocks_per_cu_for(uint32_t sps, int slicer, bool tol)
@@ -311,24 +315,7 @@ int front_blocks_per_cu_for(uint32_t sps, int slicer, bool tol)
 }
 template <int SPS> void launch_front(const FrontArgs &fa, dim3 grid, hipStream_t s, int slicer)
 {
-    if (slicer == AMPS_SLICER_PRODUCT) {
-        if (fa.tol) hipLaunchKernelGGL((recc_front_kernel<SPS, 1, false, true, AMPS_SLICER_PRODUCT>), grid, dim3(256), 0, s, fa);
-        else if (front_depth(slicer) == 2) hipLaunchKernelGGL((recc_front_kernel<SPS, 2, false, false, AMPS_SLICER_PRODUCT>), grid, dim3(256), 0, s, fa);
-        else hipLaunchKernelGGL((recc_front_kernel<SPS, 1, false, false, AMPS_SLICER_PRODUCT>), grid, dim3(256), 0, s, fa);
-        return;
-    }
-    if (slicer == AMPS_SLICER_SINE) {
-        if (fa.tol) hipLaunchKernelGGL((recc_front_kernel<SPS, 1, false, true, AMPS_SLICER_SINE>), grid, dim3(256), 0, s, fa);
-        else if (front_depth(slicer) == 2) hipLaunchKernelGGL((recc_front_kernel<SPS, 2, false, false, AMPS_SLICER_SINE>), grid, dim3(256), 0, s, fa);
-        else hipLaunchKernelGGL((recc_front_kernel<SPS, 1, false, false, AMPS_SLICER_SINE>), grid, dim3(256), 0, s, fa);
-        return;
-    }
-    if (fa.tol) { hipLaunchKernelGGL((recc_front_kernel<SPS, 1, false, true>), grid, dim3(256), 0, s, fa); return; }
-    switch (front_depth(slicer)) {
-    case 3: hipLaunchKernelGGL((recc_front_kernel<SPS, 3>), grid, dim3(256), 0, s, fa); break;
-    case 2: hipLaunchKernelGGL((recc_front_kernel<SPS, 2>), grid, dim3(256), 0, s, fa); break;
-    default: hipLaunchKernelGGL((recc_front_kernel<SPS, 1>), grid, dim3(256), 0, s, fa); break;
-    }
+    hipLaunchKernelGGL(front_kernel_for<SPS>(slicer, fa.tol != 0), grid, dim3(256), 0, s, fa);
 }
 
 bool sps_supported(uint32_t sps)
@@ -419,7 +406,7 @@ int run_iq_device(amps_recc *h, const float2 *iq, uint64_t ld, uint32_t nsamp)
         fa.n_done = h->n_done; fa.gring = h->gring; fa.ring_mask = h->ring_words - 1; fa.ring_words = h->ring_words;
         fa.det = h->det; fa.detcount = h->detcount; fa.max_chunks = h->max_chunks; fa.det_cap = h->det_cap;
         fa.tol = h->cfg.sync_tolerance;
-        fa.force_ones = (h->slicer == AMPS_SLICER_PRODUCT && h->n_done == h->origin) ? h->sps : 0u;   // spec B: no partner yet
+        fa.force_ones = ((h->slicer == AMPS_SLICER_PRODUCT || h->slicer == AMPS_SLICER_EXACT) && h->n_done == h->origin) ? h->sps : 0u;   // specs B, D: no partner yet
         fa.status = h->status; fa.dbg_d = h->dbg_d; fa.dbg_S = h->dbg_S; fa.dbg_channel = 0;
         front_housekeeping_args(h, fa);
         SpanGuard g(h, T_FRONT, P);
@@ -492,7 +479,7 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
     if (cfg->wideband_channels && (cfg->samples_per_symbol != 3 || cfg->max_samples_per_push == 0)) return -EINVAL;
     if (cfg->sync_tolerance > AMPS_RECC_MAX_SYNC_TOLERANCE) return -EINVAL;
     {
-        const uint32_t sl = cfg->flags & (AMPS_RECC_FLAG_SLICER_PRODUCT | AMPS_RECC_FLAG_SLICER_SINE | AMPS_RECC_FLAG_SLICER_ATAN);
+        const uint32_t sl = cfg->flags & (AMPS_RECC_FLAG_SLICER_PRODUCT | AMPS_RECC_FLAG_SLICER_SINE | AMPS_RECC_FLAG_SLICER_ATAN | AMPS_RECC_FLAG_SLICER_EXACT);
         if (sl & (sl - 1)) return -EINVAL;                         // at most one slicer spec
     }
     if (cfg->n_channels >= (1u << (64 - CAPQ_POS_BITS))) return -EINVAL;
@@ -517,6 +504,7 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
     h->sps = cfg->samples_per_symbol;
     h->slicer = (cfg->flags & AMPS_RECC_FLAG_SLICER_PRODUCT) ? AMPS_SLICER_PRODUCT
               : (cfg->flags & AMPS_RECC_FLAG_SLICER_SINE) ? AMPS_SLICER_SINE
+              : (cfg->flags & AMPS_RECC_FLAG_SLICER_EXACT) ? AMPS_SLICER_EXACT
               : (cfg->flags & AMPS_RECC_FLAG_SLICER_ATAN) ? AMPS_SLICER_ATAN_BOXCAR : AMPS_SLICER_DEFAULT;
     h->timing = (cfg->flags & AMPS_RECC_FLAG_TIME_KERNELS) != 0;
     h->timing_mode = h->timing ? AMPS_RECC_TIMING_ALL : AMPS_RECC_TIMING_OFF;

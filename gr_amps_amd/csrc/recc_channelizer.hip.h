@@ -450,15 +450,49 @@ template <int SL> struct ChzSlicePair {
     f2 d1, d2;               // spec A / C: the last two discriminator outputs
     f2 h1r, h1i, h2r, h2i, h3r, h3i;   // spec B: the bins one, two and three frames earlier
     uint32_t gw[2];          // SIGN bits of the statistic, newest at bit 0 (the slicer bit is the inverted sign)
+    // spec D: three sign streams per channel as shift registers (newest at bit 0) -- Im y, Im(y conj(y[n-1])), Im(y conj(y[n-3])) --
+    // and, latched every 32 frames, the previous word of Im y's signs and of the two wrap words (exact_word)
+    uint32_t sx[2], st[2], sxp[2], wpp[2], wmp[2];   // (the third stream's signs live in gw)
     __device__ __forceinline__ void reset()
     {
         const f2 z = { 0.f, 0.f };
         pr = pi = d1 = d2 = h1r = h1i = h2r = h2i = h3r = h3i = z;
         gw[0] = gw[1] = 0u;                                           // "ones before the stream": sign bits clear
+        sx[0] = sx[1] = st[0] = st[1] = sxp[0] = sxp[1] = wpp[0] = wpp[1] = wmp[0] = wmp[1] = 0u;
+    }
+    // Spec D, once per 32 frames and channel: the slicer bits of the word just completed (newest at bit 0) from the sign words,
+    // 32 frames per instruction.  delay(W, Wprev, j) = the stream j frames earlier.
+    __device__ __forceinline__ uint32_t exact_word(int e)
+    {
+        const uint32_t SX = sx[e], ST = st[e], SC = gw[e];
+        const uint32_t sx1 = __builtin_amdgcn_alignbit(sxp[e], SX, 1), sx3 = __builtin_amdgcn_alignbit(sxp[e], SX, 3);
+        const uint32_t wp = ~SX & sx1 & ST, wm = SX & ~sx1 & ~ST;       // the phase step crossed the cut: w' = +1 / -1
+        const uint32_t up = ~SX & sx3 & SC, um = SX & ~sx3 & ~SC;       // ... of the three-frame partner: w'' = +1 / -1
+        const uint32_t wp1 = __builtin_amdgcn_alignbit(wpp[e], wp, 1), wp2 = __builtin_amdgcn_alignbit(wpp[e], wp, 2);
+        const uint32_t wm1 = __builtin_amdgcn_alignbit(wmp[e], wm, 1), wm2 = __builtin_amdgcn_alignbit(wmp[e], wm, 2);
+        // K = P - N, P = up + wm + wm1 + wm2, N = um + wp + wp1 + wp2, both 0..4, bit-sliced (full adder + one increment)
+        const uint32_t ps = wm ^ wm1 ^ wm2, pc = (wm & wm1) | (wm2 & (wm ^ wm1));
+        const uint32_t p0 = ps ^ up, pk = ps & up, p1 = pc ^ pk, p2 = pc & pk;
+        const uint32_t ns = wp ^ wp1 ^ wp2, nc = (wp & wp1) | (wp2 & (wp ^ wp1));
+        const uint32_t n0 = ns ^ um, nk = ns & um, n1 = nc ^ nk, n2 = nc & nk;
+        const uint32_t e2 = ~(p2 ^ n2), e1 = ~(p1 ^ n1), e0 = ~(p0 ^ n0);
+        const uint32_t gt = (p2 & ~n2) | (e2 & ((p1 & ~n1) | (e1 & p0 & ~n0)));
+        sxp[e] = SX; wpp[e] = wp; wmp[e] = wm;
+        return gt | (e2 & e1 & e0 & ~SC);                               // K > 0, or K == 0 and Im(y conj(y[n-3])) not negative
     }
     template <int PAR> __device__ __forceinline__ void step(f2 yr, f2 yi)   // PAR = parity of the absolute frame index
     {
-        if constexpr (SL == AMPS_SLICER_PRODUCT) {
+        if constexpr (SL == AMPS_SLICER_EXACT) {
+            const f2 it = __builtin_elementwise_fma(yi, pr, -(yr * pi));       // Im(y conj(y[n-1]))
+            const f2 ic = __builtin_elementwise_fma(yi, h3r, -(yr * h3i));     // Im(y conj(y[n-3]))
+            sx[0] = __builtin_amdgcn_alignbit(sx[0], __float_as_uint(yi.x), 31);
+            sx[1] = __builtin_amdgcn_alignbit(sx[1], __float_as_uint(yi.y), 31);
+            st[0] = __builtin_amdgcn_alignbit(st[0], __float_as_uint(it.x), 31);
+            st[1] = __builtin_amdgcn_alignbit(st[1], __float_as_uint(it.y), 31);
+            gw[0] = __builtin_amdgcn_alignbit(gw[0], __float_as_uint(ic.x), 31);
+            gw[1] = __builtin_amdgcn_alignbit(gw[1], __float_as_uint(ic.y), 31);
+            h3r = h2r; h3i = h2i; h2r = pr; h2i = pi; pr = yr; pi = yi;
+        } else if constexpr (SL == AMPS_SLICER_PRODUCT) {
             // g = !signbit(yi * pr3 - yr * pi3), the partner three frames (one Manchester symbol) earlier
             const f2 sd = yi * h3r - yr * h3i;
             gw[0] = __builtin_amdgcn_alignbit(gw[0], __float_as_uint(sd.x), 31);
@@ -511,7 +545,12 @@ template <int SL> struct ChzSlicePair {
             for (int g = 0; g < 4; g++) { if (g & 1) step<1>(yr[g], yi[g]); else step<0>(yr[g], yi[g]); }
         }
     }
-    __device__ __forceinline__ uint32_t word(int e) const { return ~__builtin_bitreverse32(gw[e]); }
+    // the ring word of the 32 frames just completed (oldest frame at bit 0)
+    __device__ __forceinline__ uint32_t word(int e)
+    {
+        if constexpr (SL == AMPS_SLICER_EXACT) return __builtin_bitreverse32(exact_word(e));
+        else return ~__builtin_bitreverse32(gw[e]);
+    }
 };
 
 // The slicer of a role: NP channel pairs per lane, pairs J0 .. J0 + NP - 1.
@@ -592,6 +631,13 @@ template <int SL, bool IQ, int J0, int NP> struct ChzSlicer {
                 asm volatile("" ::: "memory");            // the state they leave is that of a fresh stream (a real branch, twice per launch)
                 S[0].reset(); S[1].reset();
             }
+            if constexpr (SL == AMPS_SLICER_EXACT) {
+                // the word boundary inside the pre-roll (f0 - 1): latch the previous-word state the first real word needs
+                if (F < f0 && ((F + NB - 1) & 31) == 31) {
+#pragma unroll
+                    for (int j = 0; j < NP; j++) { S[j].exact_word(0); S[j].exact_word(1); }
+                }
+            }
             if (F >= f0 && ((F + NB - 1) & 31) == 31) {   // 32 real frames collected (f0 is a multiple of 64)
                 // A channel's words leave as ONE 16-byte store per 128 frames (aligned group of four ring dwords): single
                 // dwords scattered over the channels' ring rows are counted -- and written -- as 32-byte sectors, 8x the 27 MB
@@ -604,7 +650,7 @@ template <int SL, bool IQ, int J0, int NP> struct ChzSlicer {
 #pragma unroll
                     for (int e = 0; e < 2; e++) {
                         uint32_t word = S[j].word(e);
-                        if (SL == AMPS_SLICER_PRODUCT && a.stream_start && F + NB - 1 == 31) word |= 7u;   // no partner yet: g = 1
+                        if ((SL == AMPS_SLICER_PRODUCT || SL == AMPS_SLICER_EXACT) && a.stream_start && F + NB - 1 == 31) word |= 7u;   // no partner yet: g = 1
                         hold[j][e][0] = hold[j][e][1]; hold[j][e][1] = hold[j][e][2]; hold[j][e][2] = hold[j][e][3]; hold[j][e][3] = word;
                     }
                 nheld++;
@@ -1050,6 +1096,7 @@ inline int channelizer_run(ChannelizerState &z, const float2 *iq, size_t nsamp, 
         if (!fused) hipLaunchKernelGGL((chz12_kernel<8, CHZ12_IQ>), g12, b12, 0, s, a);
         else if (slicer == AMPS_SLICER_PRODUCT) hipLaunchKernelGGL((chz12_kernel<8, AMPS_SLICER_PRODUCT>), g12, b12, 0, s, a);
         else if (slicer == AMPS_SLICER_SINE) hipLaunchKernelGGL((chz12_kernel<8, AMPS_SLICER_SINE>), g12, b12, 0, s, a);
+        else if (slicer == AMPS_SLICER_EXACT) hipLaunchKernelGGL((chz12_kernel<8, AMPS_SLICER_EXACT>), g12, b12, 0, s, a);
         else hipLaunchKernelGGL((chz12_kernel<8, AMPS_SLICER_ATAN_BOXCAR>), g12, b12, 0, s, a);
     }
     if (after_main) after_main(after_ctx);                            // timing: the span ends behind the filter-bank kernel, before the carry copy

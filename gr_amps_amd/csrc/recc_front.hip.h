@@ -278,6 +278,65 @@ __device__ __forceinline__ float lane63(float v)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// Bit-sliced small integers for slicer spec D: bit i of plane k = bit k of the count that belongs to sample i of a 32-sample word
+// (oldest sample at bit 0, so "j samples earlier" is a left shift).  Everything is inlined and the planes that cannot be set are
+// compile-time zeros, so the adders fold to the planes that exist (the compiler fuses the three-input forms into v_bitop3_b32).
+struct BitNum { uint32_t p[5]; };
+__device__ __forceinline__ BitNum bn_word(uint32_t w) { return BitNum{ { w, 0u, 0u, 0u, 0u } }; }
+__device__ __forceinline__ BitNum bn_shl(const BitNum &a, int j)
+{
+    BitNum r;
+#pragma unroll
+    for (int k = 0; k < 5; k++) r.p[k] = a.p[k] << j;
+    return r;
+}
+__device__ __forceinline__ BitNum bn_add(const BitNum &a, const BitNum &b)
+{
+    BitNum r;
+    uint32_t c = 0u;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const uint32_t x = a.p[k] ^ b.p[k];
+        r.p[k] = x ^ c;
+        c = (a.p[k] & b.p[k]) | (x & c);
+    }
+    return r;
+}
+// sum_{j < L} (w << j): the number of set samples among the L ending at each position, by doubling (1, 2, 4, 8 samples) and the
+// binary digits of L
+template <int L> __device__ __forceinline__ BitNum bn_window(uint32_t w)
+{
+    static_assert(L >= 1 && L <= 16, "window");
+    BitNum pw[5];
+    pw[0] = bn_word(w);
+#pragma unroll
+    for (int b = 1; b < 5; b++) pw[b] = (L >> b) ? bn_add(pw[b - 1], bn_shl(pw[b - 1], 1 << (b - 1))) : bn_word(0u);
+    BitNum acc = bn_word(0u);
+    int off = 0;
+#pragma unroll
+    for (int b = 4; b >= 0; b--)
+        if ((L >> b) & 1) { acc = bn_add(acc, bn_shl(pw[b], off)); off += 1 << b; }
+    return acc;
+}
+// slicer spec D (include/amps_recc_numerics.h) on one 32-sample window, oldest sample at bit 0: SX, ST, SC = the signs of Im x,
+// Im(x conj(x[n-1])), Im(x conj(x[n-SPS])).  Bits >= SPS + 1 of the result are exact (the wraps need one sample of history, their
+// window SPS - 1 more, the partner SPS).
+template <int SPS> __device__ __forceinline__ uint32_t exact_slice_word(uint32_t SX, uint32_t ST, uint32_t SC)
+{
+    const uint32_t sx1 = SX << 1, sxs = SX << SPS;
+    const uint32_t wp = ~SX & sx1 & ST, wm = SX & ~sx1 & ~ST;          // w'  = +1 / -1
+    const uint32_t up = ~SX & sxs & SC, um = SX & ~sxs & ~SC;          // w'' = +1 / -1
+    const BitNum P = bn_add(bn_window<SPS>(wm), bn_word(up));          // K = P - N
+    const BitNum N = bn_add(bn_window<SPS>(wp), bn_word(um));
+    uint32_t gt = 0u, eq = ~0u;
+#pragma unroll
+    for (int k = 4; k >= 0; k--) {
+        gt |= eq & P.p[k] & ~N.p[k];
+        eq &= ~(P.p[k] ^ N.p[k]);
+    }
+    return gt | (eq & ~SC);                                            // K > 0, or K == 0 and the partner product not negative
+}
+
 // BITS = true is the bit-domain form used behind the fused channelizer: the slicer bits of this launch are
 // already in the HBM ring (written by chz_fused_kernel), so a tile is just 16 dwords read from it and only the
 // correlator / emit stages (P3a, P3b) run.
@@ -290,8 +349,9 @@ __device__ __forceinline__ float lane63(float v)
 template <int SPS, int DEPTH, bool BITS = false, bool TOL = false, int SL = AMPS_SLICER_ATAN_BOXCAR>
 __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc_front_kernel(FrontArgs a)
 {
-    constexpr bool PROD = SL == AMPS_SLICER_PRODUCT;
-    static_assert(!PROD || (!BITS && SPS <= XHIST), "spec B runs on IQ");
+    constexpr bool EXACT = SL == AMPS_SLICER_EXACT;
+    constexpr bool PROD = SL == AMPS_SLICER_PRODUCT || EXACT;          // specs B and D stage the tile's raw samples in LDS
+    static_assert(!PROD || (!BITS && SPS < XHIST), "specs B / D run on IQ");
     front_housekeeping(a);
     static_assert(SPS >= 2 && SPS <= 16, "samples per symbol");
     constexpr int H = SPS - 1;                  // boxcar history
@@ -300,6 +360,7 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc
     __shared__ float    s_d_all[4][BITS ? 8 : PROD ? 2 * XBUF : 2 * DBUF];   // demod buffers (spec B: one float2 sample buffer): not used in the bit domain (keeps its LDS at 2 KB)
     __shared__ uint32_t s_g_all[4][GW32 + 2];   // [GW32] mirrors [0] so a tap can always read dwords qd, qd+1
     __shared__ uint32_t s_m_all[4][GW32];
+    __shared__ uint32_t s_x_all[EXACT ? 4 : 1][EXACT ? 3 * (GW32 + 2) : 1];   // spec D: the three sign streams as bit rings shaped like s_g
 
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -317,6 +378,7 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc
     float *s_d = s_d_all[wv];
     uint32_t *s_g = s_g_all[wv];
     uint32_t *s_m = s_m_all[wv];
+    uint32_t *s_x = s_x_all[EXACT ? wv : 0];
     // lane-constant pieces of the LDS addressing (everything else is an immediate offset)
     const int dw_off = 2 * lane + (lane >> 2);          // P1 writes: didx(DHIST + 128q + 2*lane + e)
     const int dr_off = 9 * lane;                        // P2 reads:  didx(DHIST - H + 8*lane + m)
@@ -372,6 +434,10 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc
     s_g[lane] = ~0u;
     if (lane < 2) s_g[GW32 + lane] = ~0u;
     s_m[lane] = 0u;
+    if constexpr (EXACT) {
+#pragma unroll
+        for (int u = 0; u < 3; u++) { s_x[u * (GW32 + 2) + lane] = 0u; if (lane < 2) s_x[u * (GW32 + 2) + GW32 + lane] = 0u; }
+    }
     if constexpr (!BITS) for (int i = lane; i < (PROD ? 2 * XBUF : 2 * DBUF); i += 64) s_d[i] = 0.f;
 
     float4 cur[4], nxt[DEPTH][4];                // tile k in use, tiles k+1..k+DEPTH in flight (DEPTH x 4 KiB per wave)
@@ -427,6 +493,39 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc
 #pragma unroll
             for (int m = 0; m < SPS + 8; m++) v[m] = xr[xidx(XHIST - SPS + m)];
             const bool dbg = a.dbg_d && (uint32_t)c == a.dbg_channel && k >= 0;
+            unsigned byte;
+            if constexpr (EXACT) {
+                // spec D: three sign bits per sample (Im x, Im(x conj(x[n-1])), Im(x conj(x[n-SPS]))) into three bit rings shaped
+                // like s_g; the slicer bits of the lane's eight samples then come out of a 32-sample window of those rings
+                uint32_t ax = 0u, at = 0u, ac = 0u;                  // sign bits, newest at bit 0
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const f2 x = v[SPS + q], p1 = v[SPS + q - 1], ps = v[q];
+                    const float it = __builtin_fmaf(x.y, p1.x, -(x.x * p1.y));
+                    const float ic = __builtin_fmaf(x.y, ps.x, -(x.x * ps.y));
+                    ax = __builtin_amdgcn_alignbit(ax, __float_as_uint(x.y), 31);
+                    at = __builtin_amdgcn_alignbit(at, __float_as_uint(it), 31);
+                    ac = __builtin_amdgcn_alignbit(ac, __float_as_uint(ic), 31);
+                    if (dbg) {
+                        int64_t rel = t0 + 8 * lane + q;
+                        if (rel < (int64_t)a.P) { a.dbg_d[rel] = it; a.dbg_S[rel] = ic; }
+                    }
+                }
+                uint8_t *const bx = (uint8_t *)s_x, *const bt = (uint8_t *)(s_x + (GW32 + 2)), *const bc = (uint8_t *)(s_x + 2 * (GW32 + 2));
+                const int bo = slot * (TILE / 8) + lane;
+                const uint8_t vx = (uint8_t)(__builtin_bitreverse32(ax) >> 24), vt = (uint8_t)(__builtin_bitreverse32(at) >> 24),
+                              vc = (uint8_t)(__builtin_bitreverse32(ac) >> 24);      // sample 8*lane+q at bit q
+                bx[bo] = vx; bt[bo] = vt; bc[bo] = vc;
+                if (slot == 0 && lane < 8) { bx[GW32 * 4 + lane] = vx; bt[GW32 * 4 + lane] = vt; bc[GW32 * 4 + lane] = vc; }   // mirror of dwords 0,1
+                __builtin_amdgcn_wave_barrier();                     // sign bytes visible; everybody has read the history prefix
+                // the 32 samples that end with this lane's eight: bytes bo-3 .. bo of each ring
+                const int b0 = (bo - 3) & (4 * GW32 - 1), qd = b0 >> 2;
+                uint32_t W[3];
+#pragma unroll
+                for (int u = 0; u < 3; u++)
+                    W[u] = __builtin_amdgcn_alignbyte(s_x[u * (GW32 + 2) + qd + 1], s_x[u * (GW32 + 2) + qd], (uint32_t)(b0 & 3));
+                byte = exact_slice_word<SPS>(W[0], W[1], W[2]) >> 24;
+            } else {
             uint32_t acc = 0u;                                       // sign bits, newest at bit 0
 #pragma unroll
             for (int q = 0; q < 8; q++) {
@@ -438,12 +537,13 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc
                     if (rel < (int64_t)a.P) { a.dbg_d[rel] = 0.f; a.dbg_S[rel] = rel < (int64_t)a.force_ones ? 0.f : sd; }
                 }
             }
-            unsigned byte = (~__builtin_bitreverse32(acc)) >> 24;    // g = !signbit, sample 8*lane+q at bit q
+            byte = (~__builtin_bitreverse32(acc)) >> 24;             // g = !signbit, sample 8*lane+q at bit q
+            }
             if (t0 == 0 && a.force_ones) {                           // wave-uniform: the first tile of a stream
                 const int nf = (int)a.force_ones - 8 * lane;         // samples of this lane that have no partner yet
                 if (nf > 0) byte |= nf >= 8 ? 0xffu : (1u << nf) - 1u;
             }
-            __builtin_amdgcn_wave_barrier();                         // everybody has read the history prefix
+            if constexpr (!EXACT) __builtin_amdgcn_wave_barrier();   // everybody has read the history prefix
             if (lane >= 56) {                                        // samples 496..511 become the next tile's history
                 xs[xidx(2 * (lane - 56))] = (f2){ cur[3].x, cur[3].y };
                 xs[xidx(2 * (lane - 56)) + 1] = (f2){ cur[3].z, cur[3].w };

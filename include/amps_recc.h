@@ -61,7 +61,10 @@ extern "C" {
 #define AMPS_RECC_FLAG_SLICER_PRODUCT 0x8u /* IQ / wideband seams: slicer spec B of amps_recc_numerics.h (sign of
                                                Im(x[n] conj(x[n-sps])), the telescoped form of discriminator + boxcar) */
 #define AMPS_RECC_FLAG_SLICER_SINE  0x10u /* IQ / wideband seams: slicer spec C (boxcar over Im(x[n] conj(x[n-1])): spec A without the
-                                               arctangent).  At most one of the three SLICER flags may be set */
+                                               arctangent) */
+#define AMPS_RECC_FLAG_SLICER_EXACT 0x80u /* IQ / wideband seams: slicer spec D (the sign of spec A's boxcar sum computed exactly from sign
+                                               bits and the winding number: spec A's decisions at spec C's cost).  At most one of the four
+                                               SLICER flags may be set */
 #define AMPS_RECC_FLAG_SLICER_ATAN  0x40u /* IQ / wideband seams: slicer spec A (arctangent discriminator + boxcar), explicitly.
                                                With no SLICER flag a handle uses amps_recc_default_slicer() */
 #define AMPS_RECC_FLAG_KEEP_BURSTS  0x20u /* IQ / wideband seams: also keep the 3374 captured symbol bytes of every burst (what

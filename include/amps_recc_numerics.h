@@ -65,6 +65,33 @@
  * it decodes like spec A down to 8 dB SNR.  d' is not an FM-demod float in radians; the
  * stated-tolerance intermediate of spec A stays available through amps_recc_debug_demod.
  *
+ * ---- slicer spec D, "exact-sign discriminator" (AMPS_RECC_FLAG_SLICER_EXACT) ----
+ * Only the SIGN of spec A's boxcar sum S[n] = sum_{k=n-sps+1..n} theta[k], theta[k] = arg(x[k] conj(x[k-1])) in (-pi, pi], leaves
+ * the float stage, and that sign can be had exactly without evaluating one arctangent.  With a[k] = arg x[k] (principal value):
+ *     theta[k]        = a[k] - a[k-1] - 2 pi w'[k]          w'[k]  in {-1, 0, +1}: did the phase step cross the +-pi cut
+ *     a[n] - a[n-sps] = phi[n]        + 2 pi w''[n]         phi[n] = arg(x[n] conj(x[n-sps])), the statistic of spec B
+ *  => S[n] = phi[n] + 2 pi K[n],     K[n] = w''[n] - sum_{k=n-sps+1..n} w'[k]      (the winding number spec B ignores)
+ *  => S[n] >= 0  <=>  K[n] > 0, or K[n] == 0 and phi[n] >= 0.
+ * A difference of two principal values exceeds +pi only from the lower half plane to the upper one and only if the conj-product
+ * then has a negative imaginary part (and mirrored for -pi), so every wrap is a function of three sign bits:
+ *
+ *   it = fmaf(xi[n], xr[n-1],   -(xr[n] * xi[n-1]))      Im(x[n] conj(x[n-1]))    -- the d' of spec C
+ *   ic = fmaf(xi[n], xr[n-sps], -(xr[n] * xi[n-sps]))    Im(x[n] conj(x[n-sps]))  -- the statistic of spec B (as one fma)
+ *   sx[n] = signbit(xi[n])   st = signbit(it)   sc = signbit(ic)
+ *   wp[n] = !sx[n] &  sx[n-1]   &  st        (w'[n]  = +1)        up = !sx[n] &  sx[n-sps] &  sc     (w''[n] = +1)
+ *   wm[n] =  sx[n] & !sx[n-1]   & !st        (w'[n]  = -1)        um =  sx[n] & !sx[n-sps] & !sc     (w''[n] = -1)
+ *   K     = (up + sum_{j<sps} wm[n-j]) - (um + sum_{j<sps} wp[n-j])
+ *   g[n]  = (K > 0) | (K == 0 & !sc)
+ *   g[n]  = 1 for the first sps samples of a stream (no partner yet), as in spec B; samples before the stream are +0
+ *           (sx = 0, wp = wm = 0)
+ *
+ * Four multiply-adds and three sign bits per sample; the rest is bitwise logic on 32 samples at a time.  In exact arithmetic
+ * g[n] equals spec A's bit with an ideal arctangent; in binary32 it equals the bit of the float64 libm discriminator wherever
+ * |S[n]| exceeds the rounding of the two products (tests/test_gpu_slicer_specs.py holds it to: no difference at |S| > 1e-4 rad,
+ * against spec A's own 1e-5 rad per sample) -- so spec D keeps spec A's sensitivity (no wrap, no amplitude weighting) at spec C's
+ * cost.  The FM-demod float d[n] in radians is not materialised; it stays available through amps_recc_debug_demod on a spec-A
+ * handle, and the two floats spec D does compute (it, ic) are what its debug taps return.
+ *
  * ---- which spec is the default, and what the others cost in sensitivity ----
  * AMPS_SLICER_DEFAULT = spec A.  scripts/slicer_sensitivity.py (profiles/r03/slicer_sensitivity.txt; 1000 bursts per point on the
  * IQ seam, 1248 on the wideband seam, C/N stated in a 30 kHz channel) gives the C/N at which 1 % of the seizure bursts are lost:
@@ -108,6 +135,7 @@
 #define AMPS_SLICER_ATAN_BOXCAR 0  /* spec A: discriminator + boxcar (default)                      */
 #define AMPS_SLICER_PRODUCT     1  /* spec B: sign of Im(x[n] conj(x[n-sps]))                        */
 #define AMPS_SLICER_SINE        2  /* spec C: boxcar over Im(x[n] conj(x[n-1])), no arctangent       */
+#define AMPS_SLICER_EXACT       3  /* spec D: sign of spec A's boxcar sum from sign bits and the winding number, no arctangent */
 #define AMPS_SLICER_DEFAULT     AMPS_SLICER_ATAN_BOXCAR  /* what a handle created with no SLICER flag uses (amps_recc_default_slicer) */
 
 #endif

@@ -363,9 +363,11 @@ def fm_discriminator(iq):
 class Fused:
     """CPU model of the fused MI355X seam for one channel."""
 
-    def __init__(self, channel=0, sps=10, tolerance=0, majority=False, slicer=0):
+    def __init__(self, channel=0, sps=10, tolerance=0, majority=False, slicer=None):
+        # slicer: AMPS_SLICER_* of include/amps_recc_numerics.h (0 = A, 1 = B, 2 = C, 3 = D); None = AMPS_SLICER_DEFAULT, what a product
+        # handle created with no slicer flag uses
         self._h = lib().orc_fused_new(channel, sps)
-        if slicer:
+        if slicer is not None:
             lib().orc_fused_set_slicer(self._h, int(slicer))
         if tolerance:
             lib().orc_fused_set_tolerance(self._h, int(tolerance))
@@ -394,7 +396,7 @@ class Fused:
         return d, s, g
 
 
-def fused_push_all(iq_2d, sps=10, block=None, tolerance=0, majority=False, slicer=0):
+def fused_push_all(iq_2d, sps=10, block=None, tolerance=0, majority=False, slicer=None):
     """iq_2d: complex64 [C][N]; pushes every channel (optionally in blocks) and returns all records sorted."""
     iq_2d = np.asarray(iq_2d)
     recs = []

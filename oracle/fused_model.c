@@ -57,6 +57,8 @@ struct orc_fused {
     float   *x;               /* 2*cap interleaved IQ                                      */
     float   *d, *S;           /* demod and boxcar, valid for [0, n_done)                   */
     uint8_t *g, *M;           /* slicer bits and trigger-hit bits, valid for [0, n_done)   */
+    uint8_t *sx, *wp, *wm;    /* spec D: sign of Im x and the two wrap bits per sample      */
+    size_t   wcap;
     uint64_t next_allowed;    /* run starts below this are inside an accepted burst        */
     int      have_pending;
     uint64_t pending_nc;
@@ -70,13 +72,14 @@ orc_fused_t *orc_fused_new(uint32_t channel, int sps)
 {
     orc_fused_t *f = (orc_fused_t *)calloc(1, sizeof(*f));
     f->channel = channel; f->sps = sps;
+    f->slicer = AMPS_SLICER_DEFAULT;
     orc_trigger(f->trig);
     return f;
 }
 void orc_fused_free(orc_fused_t *f)
 {
     if (!f) return;
-    free(f->x); free(f->d); free(f->S); free(f->g); free(f->M); free(f);
+    free(f->x); free(f->d); free(f->S); free(f->g); free(f->M); free(f->sx); free(f->wp); free(f->wm); free(f);
 }
 void orc_fused_set_tolerance(orc_fused_t *f, int k) { f->tol = k < 0 ? 0 : k; }
 void orc_fused_set_majority(orc_fused_t *f, int on) { f->majority = on != 0; }
@@ -97,6 +100,15 @@ static void grow(orc_fused_t *f, size_t need)
     f->g = (uint8_t *)realloc(f->g, nc);
     f->M = (uint8_t *)realloc(f->M, nc);
     f->cap = nc;
+}
+
+static void grow_wraps(orc_fused_t *f)
+{
+    if (f->wcap >= f->cap) return;
+    f->sx = (uint8_t *)realloc(f->sx, f->cap);
+    f->wp = (uint8_t *)realloc(f->wp, f->cap);
+    f->wm = (uint8_t *)realloc(f->wm, f->cap);
+    f->wcap = f->cap;
 }
 
 static inline int gbit(const orc_fused_t *f, int64_t n) { return n < 0 ? 1 : f->g[n]; }
@@ -129,6 +141,28 @@ size_t orc_fused_push(orc_fused_t *f, const float *iq, size_t n, amps_recc_burst
             const float s = a - b;
             f->S[i] = s;
             f->g[i] = signbit(s) ? 0 : 1;
+        }
+    } else if (f->slicer == AMPS_SLICER_EXACT) {
+        /* spec D: the sign of spec A's boxcar sum without the arctangent -- S[n] = phi[n] + 2 pi K[n], the winding number K from
+         * sign bits only (include/amps_recc_numerics.h).  d = Im(x conj(x[n-1])), S = Im(x conj(x[n-sps])): the two float
+         * intermediates that exist; the wrap bits of sample i live in f->M's sibling arrays below */
+        grow_wraps(f);
+        for (size_t i = lo; i < hi; i++) {
+            const float xr = f->x[2 * i], xi = f->x[2 * i + 1];
+            const float pr = i ? f->x[2 * (i - 1)] : 0.0f, pi_ = i ? f->x[2 * (i - 1) + 1] : 0.0f;
+            const float qr = i >= (size_t)sps ? f->x[2 * (i - sps)] : 0.0f, qi = i >= (size_t)sps ? f->x[2 * (i - sps) + 1] : 0.0f;
+            const float it = fmaf(xi, pr, -(xr * pi_));
+            const float ic = fmaf(xi, qr, -(xr * qi));
+            const int sx = signbit(xi) != 0, st = signbit(it) != 0, sc = signbit(ic) != 0;
+            const int sx1 = i ? f->sx[i - 1] : 0, sxs = i >= (size_t)sps ? f->sx[i - sps] : 0;
+            f->sx[i] = (uint8_t)sx;
+            f->wp[i] = (uint8_t)(!sx && sx1 && st);        /* arg x[i] - arg x[i-1] wrapped past +pi */
+            f->wm[i] = (uint8_t)(sx && !sx1 && !st);       /* ... past -pi */
+            int K = (!sx && sxs && sc) - (sx && !sxs && !sc);
+            for (int j = 0; j < sps; j++) if (i >= (size_t)j) K += (int)f->wm[i - j] - (int)f->wp[i - j];
+            f->d[i] = it;
+            f->S[i] = ic;
+            f->g[i] = i < (size_t)sps ? 1 : (uint8_t)(K > 0 || (K == 0 && !sc));   /* no partner yet: g = 1, as in spec B */
         }
     } else
     for (size_t i = lo; i < hi; i++) {

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gr_amps_amd import capi
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-specs = sys.argv[2].split(",") if len(sys.argv) > 2 else ("atan", "sine", "product")
+specs = sys.argv[2].split(",") if len(sys.argv) > 2 else ("atan", "sine", "product", "exact")
 warm = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 groups = int(sys.argv[4]) if len(sys.argv) > 4 else 0        # > 1: time ONE channel group of that many (a rank of the one-band multi-GPU split)
 NW = 1 << 27

@@ -11,7 +11,7 @@ g = torch.Generator(device="cuda")
 g.manual_seed(1)
 x = torch.view_as_complex(torch.randn(C, N, 2, device="cuda", generator=g) * 0.5)
 torch.cuda.synchronize()
-for spec in ("atan", "sine", "product"):
+for spec in ("atan", "sine", "product", "exact"):
     r = capi.Recc(n_channels=C, sps=10, max_samples=N, max_bursts=4096, time_kernels=True, slicer=spec)
     for _ in range(40):
         r.push_iq(x)

@@ -1,4 +1,4 @@
-"""Sensitivity of the three slicer specs (A atan + boxcar, B product detector, C sine discriminator) against the restated
+"""Sensitivity of the four slicer specs (A atan + boxcar, B product detector, C sine discriminator, D exact sign) against the restated
 reference chain: burst-loss and wrong-word rate over the carrier-to-noise ratio, on both seams.
 C/N is stated in a 30 kHz AMPS channel bandwidth on both seams.
 
@@ -30,7 +30,8 @@ sys.path.insert(0, ROOT)
 NB = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 SNRS = list(range(6, 19))
 SNRS_HIGH = [20, 24, 30]          # where the restated reference chain's loss floor shows (its M&M loop must lock within the 4 spare dotting bits)
-SPECS = ("atan", "product", "sine")
+SPECS = ("atan", "product", "sine", "exact")
+SKIP_REF = os.environ.get("SENS_NO_REF") == "1"       # the reference column costs most of the time; a quick A / B / C / D run skips it
 N_IQ = 40000
 FS = 30.72e6
 
@@ -103,7 +104,7 @@ def main():
     table = {}
 
     # ---------------- IQ seam
-    print("seam C/N_dB(30kHz) sent | loss A / B / C / ref | wrong-word rate A / B / C / ref (valid words)", flush=True)
+    print("seam C/N_dB(30kHz) sent | loss A / B / C / D / ref | wrong-word rate A / B / C / D / ref (valid words)", flush=True)
     for snr in SNRS + SNRS_HIGH:
         res = pool.map(iq_job, [(910000 + 1000 * snr + i, snr) for i in range(NB)], chunksize=8)
         iq = np.stack([r[0] for r in res])
@@ -173,7 +174,8 @@ def main():
                 seg = y[max(0, o4 - 6000):o4 + blen * 5 // 384 + 4000].to(torch.complex64).cpu().numpy()
                 jobs.append((seg, min10, words))
             del X
-            tot["ref"] += np.array(pool.map(ref400_job, jobs, chunksize=2)).sum(0)
+            if not SKIP_REF:
+                tot["ref"] += np.array(pool.map(ref400_job, jobs, chunksize=2)).sum(0)
         table[("wide", snr)] = tot
         table[("wide_sent", snr)] = sent_total
         print("wide %5d %5d | " % (snr, sent_total) + " / ".join("%.4f" % (1 - tot[k][0] / sent_total) for k in SPECS + ("ref",)) + " | "
@@ -189,8 +191,8 @@ def main():
             cr[k] = crossing(allsnr, loss)
         fmt = lambda v: "n/a" if v is None else "%.2f" % v
         pen = lambda k: "n/a" if (cr[k] is None or cr["atan"] is None) else "%+.2f" % (cr[k] - cr["atan"])
-        print("%-4s A %s | B %s | C %s | reference chain %s || penalty vs A: B %s dB, C %s dB, reference chain %s dB"
-              % (seam, fmt(cr["atan"]), fmt(cr["product"]), fmt(cr["sine"]), fmt(cr["ref"]), pen("product"), pen("sine"), pen("ref")))
+        print("%-4s A %s | B %s | C %s | D %s | reference chain %s || penalty vs A: B %s dB, C %s dB, D %s dB, reference chain %s dB"
+              % (seam, fmt(cr["atan"]), fmt(cr["product"]), fmt(cr["sine"]), fmt(cr["exact"]), fmt(cr["ref"]), pen("product"), pen("sine"), pen("exact"), pen("ref")))
     print("elapsed %.0f s" % (time.time() - t00))
     pool.close()
 

@@ -93,7 +93,7 @@ def test_no_register_with_a_load_in_flight_is_touched():
                                                   os.path.join(build.CSRC, "amps_recc.hip"), "-o", out],
                        check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         res = scan(open(out).read())
-    assert len(res) == 4, [r[0] for r in res]                      # the unfused form and the three slicer specs
+    assert len(res) == 5, [r[0] for r in res]                      # the unfused form and the four slicer specs
     for name, nloads, nwaits, issues in res:
         assert nloads == 48 and nwaits == 6, (name, nloads, nwaits)   # six unrolled half-steps of eight loads
         assert not issues, (name, issues[:4])

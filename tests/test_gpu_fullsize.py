@@ -17,7 +17,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-@pytest.mark.parametrize("spec,sid", [("sine", 2), ("atan", 0)])
+@pytest.mark.parametrize("spec,sid", [("sine", 2), ("atan", 0), ("exact", 3)])
 def test_bench_block_full_size_words_and_cpu_model_slice(gpu, spec, sid):
     import torch
     import bench

@@ -1,6 +1,7 @@
 """-m gpu parity tests of the atan-free slicer specs of include/amps_recc_numerics.h:
   spec B (AMPS_RECC_FLAG_SLICER_PRODUCT): the sign of Im(x[n] conj(x[n-sps])) instead of discriminator + boxcar;
-  spec C (AMPS_RECC_FLAG_SLICER_SINE):    spec A's boxcar over Im(x[n] conj(x[n-1])), no arctangent.
+  spec C (AMPS_RECC_FLAG_SLICER_SINE):    spec A's boxcar over Im(x[n] conj(x[n-1])), no arctangent;
+  spec D (AMPS_RECC_FLAG_SLICER_EXACT):   the sign of spec A's boxcar sum from sign bits and the winding number.
 Every check goes through the C ABI and compares with the CPU model (oracle/fused_model.c, orc_fused_set_slicer)
 bit for bit; the words must also equal those of the default spec A on the same bursts."""
 import numpy as np
@@ -24,7 +25,7 @@ def _channels(C, N, seed0, nb=1, snr=30.0, sps=10):
     return np.stack(iq), truth
 
 
-SPECS = [("product", 1), ("sine", 2)]
+SPECS = [("product", 1), ("sine", 2), ("exact", 3)]
 
 
 @pytest.mark.parametrize("spec,sid", SPECS)
@@ -89,7 +90,8 @@ def test_product_slicer_ragged_pushes(gpu, blocks, spec, sid):
         assert total == sum(len(t) for t in truth)
 
 
-@pytest.mark.parametrize("spec,snr", [("product", 30.0), ("product", 18.0), ("sine", 30.0), ("sine", 18.0), ("sine", 12.0)])
+@pytest.mark.parametrize("spec,snr", [("product", 30.0), ("product", 18.0), ("sine", 30.0), ("sine", 18.0), ("sine", 12.0),
+                                      ("exact", 30.0), ("exact", 18.0), ("exact", 12.0)])
 def test_product_slicer_words_equal_spec_a(gpu, snr, spec):
     """same bursts through both numeric specs: identical words, fields and validity (the run centre may move by a sample)"""
     C, N = 8, 4 * 40000
