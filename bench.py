@@ -34,12 +34,12 @@ sys.path.insert(0, ROOT)
 ALG_BYTES_PER_SYMBOL_DIRECT = 80.0   # 8 B/sample x 10 samples/symbol, IQ read once
 HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec (6290 GB/s measured copy ceiling)
 FP32_PEAK_TFLOPS = 157.3             # MI355X_MICROARCH.md: peak FP32 vector rate (packed)
-SLICERS = {"atan": "A", "product": "B", "sine": "C"}
-# C/N (30 kHz channel) at 1 % seizure-burst loss, scripts/slicer_sensitivity.py on one MI355X (profiles/r03/slicer_sensitivity.txt)
-SLICER_SENSITIVITY = {"unit": "dB C/N in 30 kHz at 1 % burst loss", "source": "profiles/r03/slicer_sensitivity.txt (1000 / 1248 bursts per point)",
-                      "wideband_seam": {"A": 9.6, "B": 11.7, "C": 13.3, "restated_reference_chain": 24.1},
-                      "iq_seam_behind_the_flow_graphs_channel_filter": {"A": 10.2, "B": 10.1, "C": 11.2, "restated_reference_chain": 24.8},
-                      "penalty_vs_A_wideband_dB": {"B": 2.0, "C": 3.7}}
+SLICERS = {"atan": "A", "product": "B", "sine": "C", "exact": "D"}
+# C/N (30 kHz channel) at 1 % seizure-burst loss, scripts/slicer_sensitivity.py on one MI355X (profiles/r04/slicer_sensitivity.txt)
+SLICER_SENSITIVITY = {"unit": "dB C/N in 30 kHz at 1 % burst loss", "source": "profiles/r04/slicer_sensitivity.txt (1000 / 1248 bursts per point)",
+                      "wideband_seam": {"A": 9.64, "B": 11.68, "C": 13.30, "D": 9.64, "restated_reference_chain": 24.3},
+                      "iq_seam_behind_the_flow_graphs_channel_filter": {"A": 10.23, "B": 10.10, "C": 11.20, "D": 10.23, "restated_reference_chain": 24.8},
+                      "penalty_vs_A_wideband_dB": {"B": 2.0, "C": 3.7, "D": 0.0}}
 
 
 def parse(argv=None):
@@ -54,8 +54,9 @@ def parse(argv=None):
                     help="a second workload reported under 'secondary' (N=1 only)")
     ap.add_argument("--slicer", default="default", choices=["default"] + list(SLICERS),
                     help="numeric spec of the slicer (include/amps_recc_numerics.h).  default = whatever a handle created with no slicer flag "
-                         "uses (amps_recc_default_slicer(): spec A, arctangent discriminator + boxcar) -- the headline is the product's default path; "
-                         "sine = spec C (the same without the arctangent), product = spec B: opt-in variants, their kernel times are reported under 'other_slicer_specs'")
+                         "uses (amps_recc_default_slicer(): spec D, the sign of the arctangent discriminator's boxcar sum computed exactly from sign "
+                         "bits and the winding number) -- the headline is the product's default path; atan = spec A (the arctangent itself, default of "
+                         "rounds 1-3), sine = spec C, product = spec B: opt-in variants, their kernel times are reported under 'other_slicer_specs'")
     ap.add_argument("--dist", default="bands", choices=["bands", "broadcast", "scatter_allgather"])
     ap.add_argument("--groups", type=int, default=0, choices=[0, 2, 4, 8],
                     help="N = 1 only: run wideband832 as ONE rank of the one-band split over that many GPUs (cfg.wideband_groups: the rank decodes one "
@@ -216,12 +217,13 @@ def chz_flops_per_frame(taps, slicer, n_channels):
     multiplies (twiddles between the passes + inside the radix-16 butterflies); slicer per active bin."""
     fold = 1024 * taps * 2 * 2
     fft = 10240 * 2 + 2816 * 6
-    per_bin = {"atan": 8 + 27 + 2, "sine": 3 + 2, "product": 3}[slicer]     # conj-product (+ arctangent) + boxcar adds
+    # conj-product (+ arctangent) + boxcar adds; spec D: two imaginary parts of conj-products (its sign logic is integer work, not flops)
+    per_bin = {"atan": 8 + 27 + 2, "sine": 3 + 2, "product": 3, "exact": 6}[slicer]
     return fold + fft + per_bin * n_channels
 
 
 def front_flops_per_sample(slicer, sps):
-    return {"atan": 8 + 27, "sine": 3, "product": 3}[slicer] + (0 if slicer == "product" else (sps - 1))
+    return {"atan": 8 + 27, "sine": 3, "product": 3, "exact": 6}[slicer] + (0 if slicer in ("product", "exact") else (sps - 1))
 
 
 def profile_traffic(key):
@@ -292,12 +294,13 @@ class SmiSampler:
 
 
 # ----------------------------------------------------------------------------------------------------- one workload
-def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, warmup, light=False):
+def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, warmup, light=False, dist_mode=None):
     """Build the resident batch, warm up, time exactly `steps` steps (barrier + synchronize on both sides,
     max over ranks) and return the result fields for this workload.  light = kernel time only (other slicer specs)."""
     from gr_amps_amd import capi
     wide = name == "wideband832"
-    one_band = wide and dist is not None and a.dist != "bands"
+    dist_mode = dist_mode or a.dist
+    one_band = wide and dist is not None and dist_mode != "bands"
     planted = None
     if wide:
         # config 3: the whole 832-channel band from one 30.72 Msps stream through the polyphase channelizer
@@ -342,7 +345,7 @@ def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, w
                 step_no[0] += 1
                 if busy[slot] is not None:
                     torch.cuda.current_stream().wait_event(busy[slot])
-                if a.dist == "broadcast":
+                if dist_mode == "broadcast":
                     if rank == 0:
                         buf.copy_(batch, non_blocking=True)
                     dist.broadcast(torch.view_as_real(buf), src=0)
@@ -436,7 +439,12 @@ def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, w
     torch.cuda.empty_cache()
     syms_per_step_rank = C * (NW / 1536.0) if wide else C * N / sps
     # whole-job symbols: every rank its own band (bands), or the ONE band the ranks split between them (one-band modes)
-    value = (832 * (NW / 1536.0) if one_band else syms_per_step_rank * world) * steps / el
+    if one_band:           # the ONE band the ranks split between them: count the channels the ranks really decode (832 // world * world
+        tc = torch.tensor([float(C)], device=dev, dtype=torch.float64)      # for a world size without a group split)
+        dist.all_reduce(tc, op=dist.ReduceOp.SUM)
+        value = float(tc.item()) * (NW / 1536.0) * steps / el
+    else:                  # every rank its own band
+        value = syms_per_step_rank * world * steps / el
     if wide:   # dominant kernel = the channelizer; algorithmic bytes = the wideband block read once (14.77 B/symbol at 832 channels)
         kms = tm["ms_channelizer"] / max(1, tm["launches_channelizer"])
         alg_bytes = 8.0 * NW
@@ -450,7 +458,8 @@ def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, w
         alg_bytes = ALG_BYTES_PER_SYMBOL_DIRECT * syms_per_step_rank
         kname = "recc_front_kernel<10,1, slicer %s>" % SLICERS[slicer]
         flops = front_flops_per_sample(slicer, sps) * float(C) * N
-        note = "streaming kernel: HBM-bound by design (%.1f flop per input byte)" % (flops / alg_bytes)
+        note = ("streaming kernel: one pass over the IQ block, %.1f flop per input byte; bound by HBM latency / bandwidth together with VALU issue "
+                "(profiles/r04/pmc_kernels.txt)" % (flops / alg_bytes))
     if light:
         return {"kernel": kname, "kernel_ms": round(kms, 4), "value": round(value / 1e6, 3), "checked": checked}, iq_base
     ach = alg_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
@@ -460,11 +469,11 @@ def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, w
     if wide and groups in (2, 4, 8):
         par = ("one band, %d interleaved channel groups (cfg.wideband_groups), this line = group %d: %d channels; every rank folds the whole stream, "
                "pass 3 of the FFT and the slicer run for the rank's own bins only%s"
-               % (groups, group, C, ("; rank 0's block by RCCL %s every step" % ("broadcast" if a.dist == "broadcast" else "scatter + all-gather")) if one_band else
+               % (groups, group, C, ("; rank 0's block by RCCL %s every step" % ("broadcast" if dist_mode == "broadcast" else "scatter + all-gather")) if one_band else
                   " (single-GPU measurement of one rank's share, --groups)"))
     elif one_band:
         par = ("%s: rank 0's block by RCCL %s every step, rank r decodes channels [%d r, %d (r+1)); the whole filter bank runs on every rank"
-               % (a.dist, "broadcast" if a.dist == "broadcast" else "scatter + all-gather", C, C))
+               % (dist_mode, "broadcast" if dist_mode == "broadcast" else "scatter + all-gather", C, C))
     else:
         par = "bands sharded x%d (one 832-channel band per GPU), no data-path collective" % world
     res = {
@@ -496,6 +505,47 @@ def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, w
     if power:
         res["power"] = power
     return res, iq_base
+
+
+def realtime_latency(torch, slicer, local, blocks=60):
+    """SURVEY.md 8d config 1: 'also report a real-time-latency run'.  HOST-resident IQ arrives in 20 ms blocks, as a receiver delivers it;
+    latency = amps_recc_push_* (H2D staging + kernels) + amps_recc_drain, per block, host clock.  Three cases: one channel and 832
+    channels at 200 ksps on the IQ seam (4000 samples per channel and block), and the full band on the wideband seam (614 400 samples
+    at 30.72 Msps per block)."""
+    from gr_amps_amd import capi, synth
+    out = {"block_ms": 20.0, "blocks_timed": blocks, "input": "host memory (pageable numpy), staged by the library inside the push",
+           "unit": "us per block: push + drain"}
+
+    def stats(lat):
+        lat = np.array(lat) * 1e6
+        return {"median_us": round(float(np.median(lat)), 1), "p99_us": round(float(np.percentile(lat, 99)), 1),
+                "fraction_of_real_time": round(float(np.median(lat)) / 20000.0, 5)}
+    n = 4000
+    for C in (1, 832):
+        base = np.stack([synth.make_channel_block(25 * n, 2, seed=c)[0] for c in range(min(C, 8))])
+        iq = np.tile(base, ((C + 7) // 8, 1))[:C]
+        with capi.Recc(n_channels=C, sps=10, max_samples=n, max_bursts=max(64, 4 * C), device=local, slicer=slicer) as r:
+            lat = []
+            for k in range(blocks + 10):
+                blk = np.ascontiguousarray(iq[:, (k % 25) * n:(k % 25 + 1) * n])
+                t0 = time.perf_counter()
+                r.push_iq(blk)
+                r.drain(copy=False)
+                lat.append(time.perf_counter() - t0)
+        out["iq_seam_%d_channels" % C] = stats(lat[10:])
+    nw = 614400
+    rng = np.random.default_rng(3)
+    wbase = (rng.standard_normal((8, nw, 2)).astype(np.float32) * 0.05).view(np.complex64)[..., 0]
+    wb = {"channels": 1024, "decim": 512, "taps_per_branch": 8, "first_channel": 96}
+    with capi.Recc(n_channels=832, sps=3, max_samples=nw // 512 + 72, max_bursts=4096, device=local, slicer=slicer, wideband=wb) as r:
+        lat = []
+        for k in range(blocks + 10):
+            t0 = time.perf_counter()
+            r.push_wideband(wbase[k % 8])
+            r.drain(copy=False)
+            lat.append(time.perf_counter() - t0)
+    out["wideband_seam_832_channels"] = stats(lat[10:])
+    return out
 
 
 def main(argv=None):
@@ -551,8 +601,8 @@ def main(argv=None):
         "dist": a.dist,
     }
     if world == 1 and not a.no_other_specs:
-        # the same workload under the other slicer specs (short runs: kernel time + the decode check), so that the cost of
-        # the arctangent of spec A -- the library's default numeric spec -- is on the record beside the headline
+        # the same workload under the other slicer specs (short runs: kernel time + the decode check), so that what the default
+        # (spec D) saves against the arctangent of spec A -- and what the cheaper specs B / C would save on top -- is on the record
         other = {}
         for sp in SLICERS:
             if sp != a.slicer:
@@ -566,6 +616,22 @@ def main(argv=None):
                             "roofline": sec["roofline"], "roofline_compute": sec["roofline_compute"]}
         if iq_base is None:
             iq_base = sec_base
+    if world == 1 and a.secondary != "none" and "secondary" in out:
+        out["secondary"]["latency"] = realtime_latency(torch, a.slicer, local)
+    if world > 1 and a.dist == "bands" and a.workload == "wideband832" and a.secondary != "none":
+        # What BASELINE configs[4] names beside the band-per-GPU headline: ONE band, its block broadcast from rank 0 over xGMI inside
+        # the timed region (RCCL ncclBroadcast through torch.distributed), every rank decoding its interleaved channel group.  A short
+        # pass, so that one driver invocation per N yields both curves; `scaling` of this entry is "strong" (one band whatever N).
+        bsteps = max(4, min(a.steps, 40))
+        b, _ = run_workload("wideband832", a, torch, dev, dist, rank, world, local, a.slicer, bsteps, min(a.warmup, 3), dist_mode="broadcast")
+        allk = torch.zeros(world, device=dev, dtype=torch.float64)         # per-rank kernel time, gathered with an all-reduce (gloo, the
+        allk[rank] = b["roofline"]["kernel_ms"]                            # test backend, has no all-gather for device tensors)
+        dist.all_reduce(allk, op=dist.ReduceOp.SUM)
+        out["secondary"] = {"workload": "wideband832, one band over all ranks (--dist broadcast)", "value": b["value"], "unit": "Msym/s", "steps": bsteps,
+                            "ms_per_step": b["ms_per_step"], "scaling": "strong", "config": b["config"],
+                            "collective": {"op": "broadcast of the step's 1 GiB fc32 block from rank 0, inside the timed region", "backend": dist.get_backend(),
+                                           "nranks": dist.get_world_size(), "bytes_per_step": 8 * b["config"]["samples_per_channel"] * 512},
+                            "kernel_ms_per_rank": [round(float(k), 4) for k in allk.tolist()], "roofline_rank0": b["roofline"]}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         if iq_base is None:
             iq_base = make_batch(torch, torch.device("cpu"), 16, 1 << 18, 10, seed=1)[1]

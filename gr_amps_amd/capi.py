@@ -23,6 +23,7 @@ FLAG_SLICER_SINE = 16
 FLAG_KEEP_BURSTS = 32
 FLAG_SLICER_ATAN = 64
 FLAG_SLICER_EXACT = 128
+FLAG_FIXED_TIMING = 256
 
 # slicer names accepted by Recc(slicer=...): numeric spec of include/amps_recc_numerics.h -> cfg flag
 _SLICER_FLAGS = {None: 0, "default": 0, "atan": FLAG_SLICER_ATAN, 0: FLAG_SLICER_ATAN, "A": FLAG_SLICER_ATAN,
@@ -96,7 +97,7 @@ EXPORTS = (
     "amps_recc_set_xlate", "amps_recc_push_raw", "amps_recc_debug_xlate", "amps_recc_set_timing",
     "amps_recc_drain_begin", "amps_recc_drain_end", "amps_recc_set_origin",
     "amps_recc_wait_event", "amps_recc_record_event", "amps_recc_refchain_symbols", "amps_recc_refchain_tables",
-    "amps_recc_drain_bursts", "amps_recc_default_slicer",
+    "amps_recc_drain_bursts", "amps_recc_default_slicer", "amps_recc_debug_exact_slice",
 )
 
 _lib = None
@@ -190,7 +191,7 @@ class Recc:
 
     def __init__(self, n_channels=1, sps=10, max_samples=0, max_bursts=1024, device=-1, time_kernels=False,
                  stream=None, wideband=None, majority=False, unfused_wideband=False, sync_tolerance=0, slicer="default",
-                 sync_torch=True, keep_bursts=False):
+                 sync_torch=True, keep_bursts=False, fixed_timing=False):
         L = load()
         if isinstance(slicer, bool) or slicer not in _SLICER_FLAGS:        # a typo must not run a different numeric spec silently
             raise ValueError("slicer must be one of %r" % sorted(map(str, _SLICER_FLAGS)))
@@ -207,7 +208,7 @@ class Recc:
         cfg.flags = ((FLAG_TIME_KERNELS if time_kernels else 0) | (FLAG_MAJORITY if majority else 0)
                      | (FLAG_UNFUSED_WIDEBAND if unfused_wideband else 0)
                      | _SLICER_FLAGS[slicer]
-                     | (FLAG_KEEP_BURSTS if keep_bursts else 0))
+                     | (FLAG_KEEP_BURSTS if keep_bursts else 0) | (FLAG_FIXED_TIMING if fixed_timing else 0))
         cfg.stream = stream
         cfg.sync_tolerance = sync_tolerance
         if wideband:

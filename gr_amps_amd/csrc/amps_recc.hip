@@ -273,7 +273,7 @@ int front_depth(int slicer)
     static int env = -1;
     if (env < 0) { const char *e = std::getenv("AMPS_RECC_DEPTH"); env = e ? std::atoi(e) : 0; if (env < 0 || env > 3) env = 0; }
     if (env) return env;
-    return slicer == AMPS_SLICER_ATAN_BOXCAR ? 1 : 2;
+    return (slicer == AMPS_SLICER_ATAN_BOXCAR || slicer == AMPS_SLICER_EXACT) ? 1 : 2;   // spec D (round 4): 0.3285 at depth 1 against 0.3370 at depth 2 -- its sign logic is VALU work the fourth wave hides
 }
 typedef void (*front_kernel_t)(FrontArgs);
 // the instantiation of the streaming kernel for (samples per symbol, slicer spec, tolerant sync, tiles in flight)
@@ -360,6 +360,7 @@ static void launch_resolve(amps_recc *h, ResolveArgs &ra, hipStream_t s)
     ra.gring = h->gring; ra.ring_mask = h->ring_words - 1; ra.ring_words = h->ring_words; ra.cap_words = resolve_cap_words(h->sps);
     ra.records = h->records; ra.nrecords = h->nrecords; ra.rec_cap = h->cfg.max_bursts; ra.status = h->status;
     ra.majority = (h->cfg.flags & AMPS_RECC_FLAG_MAJORITY) ? 1u : 0u;
+    ra.track = (h->cfg.flags & AMPS_RECC_FLAG_FIXED_TIMING) ? 0u : 1u;
     ra.burst_syms = h->bsym_dev_buf[h->cur_buf];
     ra.done_blocks = h->done_blocks; ra.hdr_host = h->hdr_dev + HDR_STRIDE * h->cur_buf;
     ra.capq = h->capq; ra.capq_count = h->capq_count; ra.capq_cap = h->cfg.max_bursts;
@@ -1016,6 +1017,28 @@ int amps_recc_drain(amps_recc_t *h, amps_recc_burst_t *out, size_t cap, size_t *
     int rc = amps_recc_drain_begin(h);
     if (rc) return rc;
     return amps_recc_drain_end(h, out, cap, nout);
+}
+
+int amps_recc_debug_exact_slice(int form, int sps, const uint32_t *in, uint32_t *out)
+{
+    if (!in || !out) return -EINVAL;
+    if (form == 1) {
+        if (sps != 3) return -EINVAL;
+        out[0] = exact_slice_word3(in[0], in[1], in[2], in[3], in[4], in[5], out[1], out[2]);
+        return 0;
+    }
+    if (form != 0) return -EINVAL;
+    switch (sps) {
+    case 3: out[0] = exact_slice_word<3>(in[0], in[1], in[2]); break;
+    case 4: out[0] = exact_slice_word<4>(in[0], in[1], in[2]); break;
+    case 5: out[0] = exact_slice_word<5>(in[0], in[1], in[2]); break;
+    case 6: out[0] = exact_slice_word<6>(in[0], in[1], in[2]); break;
+    case 8: out[0] = exact_slice_word<8>(in[0], in[1], in[2]); break;
+    case 10: out[0] = exact_slice_word<10>(in[0], in[1], in[2]); break;
+    case 12: out[0] = exact_slice_word<12>(in[0], in[1], in[2]); break;
+    default: return -EINVAL;
+    }
+    return 0;
 }
 
 int amps_recc_debug_demod(amps_recc_t *h, const float *iq, size_t nsamp, int mem, float *demod, float *soft, uint8_t *hard)

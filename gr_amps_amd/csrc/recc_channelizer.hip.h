@@ -439,6 +439,9 @@ __device__ __forceinline__ void chz_ring_wait(cf2 (&ring)[4][P + 4])
 // steps in a four-slot ring of 4 x 4 frame buffers = 136 KB of LDS; every role stays below 168 VGPRs: three waves per SIMD.
 // The unfused form is the same kernel with a different epilogue (MODE = CHZ12_IQ: the bins leave as 32-byte runs of the
 // channel-major block), so fused and unfused forms stay bit-identical by construction.
+#ifndef CHZ_EXACT_P3_WITH_P2
+#define CHZ_EXACT_P3_WITH_P2 0       // spec D: pass 3 in the pass-2 role's waves (as under spec A) instead of the slicer role's
+#endif
 constexpr int CHZ_SLOTS = 4;                                     // half-batches in flight
 constexpr int CHZ_PREROLL = 8;                                   // frames re-run in front of a workgroup's range (two half-batches)
 constexpr int CHZ12_IQ = -1;                                     // MODE: write the channel-major block; >= 0: AMPS_SLICER_* fused behind the FFT
@@ -464,21 +467,10 @@ template <int SL> struct ChzSlicePair {
     // 32 frames per instruction.  delay(W, Wprev, j) = the stream j frames earlier.
     __device__ __forceinline__ uint32_t exact_word(int e)
     {
-        const uint32_t SX = sx[e], ST = st[e], SC = gw[e];
-        const uint32_t sx1 = __builtin_amdgcn_alignbit(sxp[e], SX, 1), sx3 = __builtin_amdgcn_alignbit(sxp[e], SX, 3);
-        const uint32_t wp = ~SX & sx1 & ST, wm = SX & ~sx1 & ~ST;       // the phase step crossed the cut: w' = +1 / -1
-        const uint32_t up = ~SX & sx3 & SC, um = SX & ~sx3 & ~SC;       // ... of the three-frame partner: w'' = +1 / -1
-        const uint32_t wp1 = __builtin_amdgcn_alignbit(wpp[e], wp, 1), wp2 = __builtin_amdgcn_alignbit(wpp[e], wp, 2);
-        const uint32_t wm1 = __builtin_amdgcn_alignbit(wmp[e], wm, 1), wm2 = __builtin_amdgcn_alignbit(wmp[e], wm, 2);
-        // K = P - N, P = up + wm + wm1 + wm2, N = um + wp + wp1 + wp2, both 0..4, bit-sliced (full adder + one increment)
-        const uint32_t ps = wm ^ wm1 ^ wm2, pc = (wm & wm1) | (wm2 & (wm ^ wm1));
-        const uint32_t p0 = ps ^ up, pk = ps & up, p1 = pc ^ pk, p2 = pc & pk;
-        const uint32_t ns = wp ^ wp1 ^ wp2, nc = (wp & wp1) | (wp2 & (wp ^ wp1));
-        const uint32_t n0 = ns ^ um, nk = ns & um, n1 = nc ^ nk, n2 = nc & nk;
-        const uint32_t e2 = ~(p2 ^ n2), e1 = ~(p1 ^ n1), e0 = ~(p0 ^ n0);
-        const uint32_t gt = (p2 & ~n2) | (e2 & ((p1 & ~n1) | (e1 & p0 & ~n0)));
-        sxp[e] = SX; wpp[e] = wp; wmp[e] = wm;
-        return gt | (e2 & e1 & e0 & ~SC);                               // K > 0, or K == 0 and Im(y conj(y[n-3])) not negative
+        uint32_t wp, wm;
+        const uint32_t g = exact_slice_word3(sx[e], st[e], gw[e], sxp[e], wpp[e], wmp[e], wp, wm);   // recc_front.hip.h
+        sxp[e] = sx[e]; wpp[e] = wp; wmp[e] = wm;
+        return g;
     }
     template <int PAR> __device__ __forceinline__ void step(f2 yr, f2 yi)   // PAR = parity of the absolute frame index
     {
@@ -734,7 +726,7 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
     // Which role runs pass 3.  Behind the cheap slicers (specs B, C: 7 instructions per channel pair and frame) it shares the
     // slicer's waves; spec A's arctangent makes the slicer the longest chain of a time step (46 instructions per pair and
     // frame), so there pass 3 moves to the pass-2 waves (spec A 0.537 -> 0.517 ms, spec C 0.399 -> 0.414 if it moved too).
-    constexpr bool P3_WITH_P2 = !IQ && SL == AMPS_SLICER_ATAN_BOXCAR;   // (handing one of the slicer's two channel pairs to the pass-2 role instead: 0.518 against 0.494)
+    constexpr bool P3_WITH_P2 = !IQ && (SL == AMPS_SLICER_ATAN_BOXCAR || (SL == AMPS_SLICER_EXACT && CHZ_EXACT_P3_WITH_P2));   // (handing one of the slicer's two channel pairs to the pass-2 role instead: 0.518 against 0.494)
     const int wf = wave & 3;                                            // frame of a half-batch this wave transforms (roles 1, 2)
     // Pass 3 produces the bins n = i (mod 64) from the points i + 64 r: a handle that decodes one channel group only needs the grp_w
     // residues of its group, so the four frames of a half-batch pack into 4 grp_w lanes: virtual lane v = 64 wf + lane transforms

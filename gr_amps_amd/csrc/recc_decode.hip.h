@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "amps_recc.h"
+#include "amps_recc_numerics.h"
 
 namespace amps {
 
@@ -218,6 +219,7 @@ struct DecodeCore {
     int8_t   ok[35];
     int8_t   flip[35][3];
     int8_t   rr[8];                             // repeat whose bits become word_dec[w]
+    int8_t   dly[AMPS_TRACK_BLOCKS];            // samples the sampling instants of tracking block b were moved by (capture from the bit ring)
     amps_recc_burst_t rec;                      // staged record (728 B), copied out coalesced
 };
 struct DecodeScratch {
@@ -271,25 +273,68 @@ __device__ __forceinline__ void manchester_from_sym(DecodeCore &s, const uint8_t
     Sync::sync();
 }
 
-// The same straight from slicer bits: symbol i of the capture is bit nc + sps (i + 1) of the channel's stream; `ring` holds
-// the stream's 64-bit words from word w0 on (LDS).  Bits cannot be non-binary.
+// The same straight from slicer bits, with the capture's timing tracking (CPU model: capture() of
+// oracle/fused_model.c).  Symbol i of the capture is bit nc + sps (i + 1) + dly(block of i) of the channel's stream; `ring` holds
+// the stream's 64-bit words from word w0 on (LDS), starting early enough for the trigger in front of the capture.  The burst is
+// walked in AMPS_TRACK_BLOCKS blocks of at most 55 bits, a lane per bit: the trigger's 37 bits (measured only), the coded DCC
+// with the first repeat, then the other 34 repeats.  Every lane fetches the sps + 1 slicer bits from its pair's first sampling
+// instant to the second; where the pair is a valid Manchester bit (a != b) the number of bits in between that still equal a says
+// how late the mid-bit transition came.  The two polarities are summed separately with ballots per bit plane of that count
+// (scalar population counts, no cross-lane adds) and the block moves everything behind it by a sample if
+// mean(e | a = 1) + mean(e | a = 0) leaves [-1, 1].  track = false (AMPS_RECC_FLAG_FIXED_TIMING) never moves.
+// Bits cannot be non-binary.
+constexpr int TRACK_PRE_BITS = AMPS_RECC_TRIGGER_SYMS / 2;     // 37 bits of trigger in front of the capture
+__host__ __device__ constexpr uint32_t capture_lead(uint32_t sps) { return sps * (AMPS_RECC_TRIGGER_SYMS - 1) + AMPS_TRACK_BLOCKS; }   // samples in front of n_c a capture reads
+__device__ __forceinline__ uint64_t capture_first_word(uint64_t nc, uint32_t sps)
+{
+    const uint64_t lead = capture_lead(sps);
+    return (nc > lead ? nc - lead : 0ull) >> 6;
+}
 template <class Sync>
-__device__ __forceinline__ void manchester_from_ring(DecodeCore &s, const uint64_t *ring, uint64_t nc, uint64_t w0, uint32_t sps, int lane)
+__device__ __forceinline__ void manchester_from_ring(DecodeCore &s, const uint64_t *ring, uint64_t nc, uint64_t w0, uint32_t sps, int lane, bool track)
 {
     decode_core_begin(s, lane);
     Sync::sync();
     const uint32_t *r32 = (const uint32_t *)ring;
-    const uint64_t base = nc + sps - (w0 << 6);                 // bit offset of symbol 0 inside the window (< 2^20)
-#pragma unroll 9
-    for (int it = 0; it < 27; it++) {
-        const int k = lane + 64 * it;
-        if (k < 1687) {
-            const uint32_t na = (uint32_t)base + sps * (uint32_t)(2 * k), nb = na + sps;
-            const unsigned sa = (r32[na >> 5] >> (na & 31)) & 1u, sb = (r32[nb >> 5] >> (nb & 31)) & 1u;
-            const bool same = sa == sb;
-            s.bits[BOFF + k] = (uint8_t)(same ? (sa ^ 1u) : sb);
-            if (same) atomicAdd(&s.bad[k < 7 ? 0 : 1 + (k - 7) / 240], 1u);
+    const int32_t base = (int32_t)(nc - (w0 << 6));              // bit offset of n_c inside the window (< 2^20)
+    const uint32_t midmask = (1u << (sps - 1)) - 1u;
+    int dly = 0, k0 = -TRACK_PRE_BITS;
+#pragma unroll 1
+    for (int b = 0; b < AMPS_TRACK_BLOCKS; b++) {
+        const int nb = b == 0 ? TRACK_PRE_BITS : b == 1 ? 7 + AMPS_RECC_WORD_BITS : AMPS_RECC_WORD_BITS;
+        const int k = k0 + lane;
+        const bool on = lane < nb;
+        const uint32_t na = (uint32_t)(base + (int32_t)sps * (2 * k + 1) + dly);     // first sampling instant of bit k
+        const uint32_t q = on ? na >> 5 : 0u;
+        const uint32_t w = __builtin_amdgcn_alignbit(r32[q + 1], r32[q], na & 31u);  // bits na .. na + 31
+        const uint32_t sa = w & 1u, sb = (w >> sps) & 1u;
+        const bool same = sa == sb;
+        if (on && k >= 0) s.bits[BOFF + k] = (uint8_t)(same ? (sa ^ 1u) : sb);
+        // bad pairs per record field: block 1 holds the DCC (bits 0..6) and repeat 0 of word 0, every later block lies inside one word
+        {
+            const uint64_t bad = __ballot(on && k >= 0 && same);
+            if (lane == 0 && b >= 1) {
+                if (b == 1) { s.bad[0] += (uint32_t)__popcll(bad & 0x7full); s.bad[1] += (uint32_t)__popcll(bad >> 7); }
+                else s.bad[1 + (k0 - 7) / 240] += (uint32_t)__popcll(bad);
+            }
         }
+        if (lane == 0) s.dly[b] = (int8_t)dly;
+        if (track) {
+            const uint32_t mid = (w >> 1) & midmask;
+            const uint32_t cnt = (uint32_t)__popc(sa ? mid : (~mid & midmask));       // bits between the two instants that still equal a
+            const bool v1 = on && !same && sa, v0 = on && !same && !sa;
+            int sum1 = 0, sum0 = 0;
+#pragma unroll
+            for (int pl = 0; pl < 4; pl++) {                                          // cnt <= sps - 1 <= 11
+                sum1 += __popcll(__ballot(v1 && ((cnt >> pl) & 1u))) << pl;
+                sum0 += __popcll(__ballot(v0 && ((cnt >> pl) & 1u))) << pl;
+            }
+            const int n1 = __popcll(__ballot(v1)), n0 = __popcll(__ballot(v0));
+            const int E1 = 2 * sum1 - (int)(sps - 1) * n1, E0 = 2 * sum0 - (int)(sps - 1) * n0;
+            const int lhs = E1 * n0 + E0 * n1, rhs = 2 * n0 * n1;
+            if (rhs > 0) dly += lhs > rhs ? 1 : lhs < -rhs ? -1 : 0;
+        }
+        k0 += nb;
     }
     Sync::sync();
 }

@@ -278,63 +278,87 @@ __device__ __forceinline__ float lane63(float v)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-// Bit-sliced small integers for slicer spec D: bit i of plane k = bit k of the count that belongs to sample i of a 32-sample word
-// (oldest sample at bit 0, so "j samples earlier" is a left shift).  Everything is inlined and the planes that cannot be set are
-// compile-time zeros, so the adders fold to the planes that exist (the compiler fuses the three-input forms into v_bitop3_b32).
-struct BitNum { uint32_t p[5]; };
-__device__ __forceinline__ BitNum bn_word(uint32_t w) { return BitNum{ { w, 0u, 0u, 0u, 0u } }; }
-__device__ __forceinline__ BitNum bn_shl(const BitNum &a, int j)
+// Bit-sliced small SIGNED integers for slicer spec D: bit i of plane k = bit k of the two's complement number that belongs to sample
+// i of a 32-sample word (oldest sample at bit 0, so "j samples earlier" is a left shift); plane W - 1 is the sign.  One chain of
+// signed adds for K = w'' - sum w' instead of two unsigned ones (wraps past +pi and past -pi counted apart, then compared): 63
+// word operations per 32 samples at 10 samples per symbol instead of 88.  Plain C: the same functions run on the host for
+// tests/test_cpu_exact_slicer.py (amps_recc_debug_exact_slice).
+template <int W> struct SBits { uint32_t p[W]; };
+__host__ __device__ constexpr int sbits_width(int L) { int w = 1; while ((1 << (w - 1)) <= L) w++; return w; }   // planes that hold -L .. L
+template <int W> __host__ __device__ __forceinline__ SBits<W> sb_shl(const SBits<W> &a, int j)
 {
-    BitNum r;
+    SBits<W> r;
 #pragma unroll
-    for (int k = 0; k < 5; k++) r.p[k] = a.p[k] << j;
+    for (int k = 0; k < W; k++) r.p[k] = a.p[k] << j;
     return r;
 }
-__device__ __forceinline__ BitNum bn_add(const BitNum &a, const BitNum &b)
+// a + b in WR planes, both sign-extended (the caller picks WR wide enough for the sum)
+template <int WR, int WA, int WB> __host__ __device__ __forceinline__ SBits<WR> sb_add(const SBits<WA> &a, const SBits<WB> &b)
 {
-    BitNum r;
+    SBits<WR> r;
     uint32_t c = 0u;
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
-        const uint32_t x = a.p[k] ^ b.p[k];
+    for (int k = 0; k < WR; k++) {
+        const uint32_t pa = a.p[k < WA ? k : WA - 1], pb = b.p[k < WB ? k : WB - 1];
+        const uint32_t x = pa ^ pb;
         r.p[k] = x ^ c;
-        c = (a.p[k] & b.p[k]) | (x & c);
+        c = (pa & pb) | (x & c);
     }
     return r;
 }
-// sum_{j < L} (w << j): the number of set samples among the L ending at each position, by doubling (1, 2, 4, 8 samples) and the
-// binary digits of L
-template <int L> __device__ __forceinline__ BitNum bn_window(uint32_t w)
+// sum_{j < L} (t << j) for t in {-1, 0, +1} per sample: the L samples ending at each position, by doubling (1, 2, 4, 8, 16 samples)
+// and the binary digits of L
+template <int L> __host__ __device__ __forceinline__ SBits<sbits_width(L)> sb_window(const SBits<2> &t)
 {
     static_assert(L >= 1 && L <= 16, "window");
-    BitNum pw[5];
-    pw[0] = bn_word(w);
-#pragma unroll
-    for (int b = 1; b < 5; b++) pw[b] = (L >> b) ? bn_add(pw[b - 1], bn_shl(pw[b - 1], 1 << (b - 1))) : bn_word(0u);
-    BitNum acc = bn_word(0u);
+    constexpr int WR = sbits_width(L);
+    const SBits<2> s1 = t;
+    SBits<3> s2{}; SBits<4> s4{}; SBits<5> s8{}; SBits<6> s16{};
+    if constexpr (L >= 2) s2 = sb_add<3>(s1, sb_shl(s1, 1));
+    if constexpr (L >= 4) s4 = sb_add<4>(s2, sb_shl(s2, 2));
+    if constexpr (L >= 8) s8 = sb_add<5>(s4, sb_shl(s4, 4));
+    if constexpr (L >= 16) s16 = sb_add<6>(s8, sb_shl(s8, 8));
+    SBits<WR> acc{};
     int off = 0;
-#pragma unroll
-    for (int b = 4; b >= 0; b--)
-        if ((L >> b) & 1) { acc = bn_add(acc, bn_shl(pw[b], off)); off += 1 << b; }
+    if constexpr (L & 16) { acc = sb_add<WR>(acc, sb_shl(s16, off)); off += 16; }
+    if constexpr (L & 8) { acc = sb_add<WR>(acc, sb_shl(s8, off)); off += 8; }
+    if constexpr (L & 4) { acc = sb_add<WR>(acc, sb_shl(s4, off)); off += 4; }
+    if constexpr (L & 2) { acc = sb_add<WR>(acc, sb_shl(s2, off)); off += 2; }
+    if constexpr (L & 1) { acc = sb_add<WR>(acc, sb_shl(s1, off)); off += 1; }
     return acc;
 }
 // slicer spec D (include/amps_recc_numerics.h) on one 32-sample window, oldest sample at bit 0: SX, ST, SC = the signs of Im x,
-// Im(x conj(x[n-1])), Im(x conj(x[n-SPS])).  Bits >= SPS + 1 of the result are exact (the wraps need one sample of history, their
+// Im(x conj(x[n-1])), Im(x conj(x[n-SPS])).  Bits >= SPS of the result are exact (the wraps need one sample of history, their
 // window SPS - 1 more, the partner SPS).
-template <int SPS> __device__ __forceinline__ uint32_t exact_slice_word(uint32_t SX, uint32_t ST, uint32_t SC)
+template <int SPS> __host__ __device__ __forceinline__ uint32_t exact_slice_word(uint32_t SX, uint32_t ST, uint32_t SC)
 {
     const uint32_t sx1 = SX << 1, sxs = SX << SPS;
     const uint32_t wp = ~SX & sx1 & ST, wm = SX & ~sx1 & ~ST;          // w'  = +1 / -1
     const uint32_t up = ~SX & sxs & SC, um = SX & ~sxs & ~SC;          // w'' = +1 / -1
-    const BitNum P = bn_add(bn_window<SPS>(wm), bn_word(up));          // K = P - N
-    const BitNum N = bn_add(bn_window<SPS>(wp), bn_word(um));
-    uint32_t gt = 0u, eq = ~0u;
+    const SBits<2> t = { { wp | wm, wp } };                            // -w' per sample: -1 where the step wrapped past +pi, +1 past -pi
+    const SBits<2> u = { { up | um, um } };                            // +w''
+    constexpr int WK = sbits_width(SPS + 1);
+    const SBits<WK> K = sb_add<WK>(sb_window<SPS>(t), u);              // K = w'' - sum w'
+    uint32_t any = 0u;
 #pragma unroll
-    for (int k = 4; k >= 0; k--) {
-        gt |= eq & P.p[k] & ~N.p[k];
-        eq &= ~(P.p[k] ^ N.p[k]);
-    }
-    return gt | (eq & ~SC);                                            // K > 0, or K == 0 and the partner product not negative
+    for (int k = 0; k < WK; k++) any |= K.p[k];
+    return ~K.p[WK - 1] & (any | ~SC);                                 // K > 0, or K == 0 and the partner product not negative
+}
+// the same for the filter bank's slicer (3 frames per symbol), whose sign words are shift registers with the NEWEST frame at bit 0
+// and the previous 32 frames in a second word: delay j = funnel shift.  wp_out / wm_out: the wrap words the next call needs.
+__host__ __device__ __forceinline__ uint32_t exact_funnel(uint32_t prev, uint32_t cur, int j) { return (cur >> j) | (prev << (32 - j)); }
+__host__ __device__ __forceinline__ uint32_t exact_slice_word3(uint32_t SX, uint32_t ST, uint32_t SC, uint32_t sx_prev, uint32_t wp_prev, uint32_t wm_prev,
+                                                                uint32_t &wp_out, uint32_t &wm_out)
+{
+    const uint32_t sx1 = exact_funnel(sx_prev, SX, 1), sx3 = exact_funnel(sx_prev, SX, 3);
+    const uint32_t wp = ~SX & sx1 & ST, wm = SX & ~sx1 & ~ST;          // the phase step crossed the cut: w' = +1 / -1
+    const uint32_t up = ~SX & sx3 & SC, um = SX & ~sx3 & ~SC;          // ... of the three-frame partner: w'' = +1 / -1
+    const uint32_t wp1 = exact_funnel(wp_prev, wp, 1), wp2 = exact_funnel(wp_prev, wp, 2);
+    const uint32_t wm1 = exact_funnel(wm_prev, wm, 1), wm2 = exact_funnel(wm_prev, wm, 2);
+    const SBits<2> t0 = { { wp | wm, wp } }, t1 = { { wp1 | wm1, wp1 } }, t2 = { { wp2 | wm2, wp2 } }, u = { { up | um, um } };
+    const SBits<4> K = sb_add<4>(sb_add<3>(t0, t1), sb_add<3>(t2, u));  // K = w'' - (w'[n] + w'[n-1] + w'[n-2]), -4 .. 4
+    wp_out = wp; wm_out = wm;
+    return ~K.p[3] & (K.p[0] | K.p[1] | K.p[2] | ~SC);                  // K > 0, or K == 0 and Im(y conj(y[n-3])) not negative
 }
 
 // BITS = true is the bit-domain form used behind the fused channelizer: the slicer bits of this launch are

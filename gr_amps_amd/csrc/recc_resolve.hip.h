@@ -37,6 +37,7 @@ struct ResolveArgs {
     uint32_t *nrecords;        // atomic
     uint32_t rec_cap;
     uint32_t majority;         // decode mode (AMPS_RECC_FLAG_MAJORITY)
+    uint32_t track;            // timing tracking inside a capture (off: AMPS_RECC_FLAG_FIXED_TIMING)
     uint8_t *burst_syms;       // optional [rec_cap][3374]: the captured symbols of record `slot` (AMPS_RECC_FLAG_KEEP_BURSTS)
     uint32_t *done_blocks;     // [1 + DONE_GROUPS] workgroups of this launch that have finished (the last one publishes the header; see DONE_GROUPS)
     uint32_t *hdr_host;        // mapped pinned {nrecords, status} of the record list: what a drain reads, no copy on the stream
@@ -55,7 +56,7 @@ struct ResolveArgs {
 constexpr int CAP_WAVES = 4;               // waves of a workgroup that decode captures side by side
 // dynamic LDS of the kernel: per decoding wave one DecodeCore and the ring words of one capture
 __host__ __device__ constexpr uint32_t resolve_cap_stride(uint32_t cap_words) { return (uint32_t)((sizeof(DecodeCore) + 7) / 8) + cap_words; }   // in 8-byte words
-inline uint32_t resolve_cap_words(uint32_t sps) { return (AMPS_RECC_CAPTURE_SYMS * sps) / 64 + 3; }
+inline uint32_t resolve_cap_words(uint32_t sps) { return (AMPS_RECC_CAPTURE_SYMS * sps + sps + capture_lead(sps) + AMPS_TRACK_BLOCKS) / 64 + 4; }   // + one dword of read-ahead for the funnel shift
 inline size_t resolve_dyn_lds(uint32_t sps) { return (size_t)CAP_WAVES * resolve_cap_stride(resolve_cap_words(sps)) * 8; }
 
 // One accepted capture (channel c, symbol-timing position nc), by all 64 lanes of one wave: ring words -> Manchester bits ->
@@ -72,8 +73,8 @@ __device__ __forceinline__ void capture_gather_wave(const ResolveArgs &a, uint32
 {
     uint64_t *s_ring = scratch + (sizeof(DecodeCore) + 7) / 8;
     const uint64_t *ring = a.gring + (uint64_t)c * a.ring_words;
-    const uint64_t w0 = (nc + a.sps) >> 6;
-    const int nw = (int)(((nc + (uint64_t)a.sps * AMPS_RECC_CAPTURE_SYMS) >> 6) - w0) + 1;
+    const uint64_t w0 = capture_first_word(nc, a.sps);
+    const int nw = (int)(((nc + (uint64_t)a.sps * (AMPS_RECC_CAPTURE_SYMS + 1) + AMPS_TRACK_BLOCKS + 32) >> 6) - w0) + 1;   // + the funnel shift's second dword
     // eight loads in flight per lane, not a load-wait-store loop of one round trip per 64 words (sps 10: nine of them)
     for (int i0 = 0; i0 < nw; i0 += 512) {
         uint64_t v[8];
@@ -95,8 +96,8 @@ __device__ __forceinline__ void capture_decode_wave(const ResolveArgs &a, uint32
 {
     DecodeCore &k = *(DecodeCore *)scratch;
     const uint64_t *s_ring = scratch + (sizeof(DecodeCore) + 7) / 8;
-    const uint64_t w0 = (nc + a.sps) >> 6;
-    manchester_from_ring<WaveSync>(k, s_ring, nc, w0, a.sps, lane);
+    const uint64_t w0 = capture_first_word(nc, a.sps);
+    manchester_from_ring<WaveSync>(k, s_ring, nc, w0, a.sps, lane, a.track != 0);
     tl.mark(0);
     decode_core_wave<WaveSync>(k, c, nc, nullptr, a.majority != 0, lane, tl);
 }
@@ -106,10 +107,11 @@ __device__ __forceinline__ void capture_store_wave(const ResolveArgs &a, uint64_
     decode_core_store(k, a.records + slot, lane);
     if (a.burst_syms) {
         const uint64_t *s_ring = scratch + (sizeof(DecodeCore) + 7) / 8;
-        const uint64_t w0 = (nc + a.sps) >> 6;
+        const uint64_t w0 = capture_first_word(nc, a.sps);
         uint8_t *dst = a.burst_syms + (uint64_t)slot * AMPS_RECC_CAPTURE_SYMS;
         for (int i = lane; i < AMPS_RECC_CAPTURE_SYMS; i += 64) {
-            const uint64_t n = nc + (uint64_t)a.sps * (uint64_t)(i + 1);
+            const int kb = i >> 1, blk = kb < 7 + AMPS_RECC_WORD_BITS ? 1 : 2 + (kb - 7 - AMPS_RECC_WORD_BITS) / AMPS_RECC_WORD_BITS;   // tracking block of the symbol's bit
+            const uint64_t n = (uint64_t)((int64_t)nc + (int64_t)a.sps * (i + 1) + k.dly[blk]);
             dst[i] = (uint8_t)((s_ring[(n >> 6) - w0] >> (n & 63)) & 1ull);
         }
     }
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(THREADS, 4) void recc_resolve_kernel(ResolveArgs a)
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     RTL(0);
     const uint64_t span_hold = (uint64_t)a.sps * (AMPS_RECC_CAPTURE_SYMS + AMPS_RECC_TRIGGER_SYMS);
-    const uint64_t span_done = (uint64_t)a.sps * (AMPS_RECC_CAPTURE_SYMS + 1);
+    const uint64_t span_done = (uint64_t)a.sps * (AMPS_RECC_CAPTURE_SYMS + 1) + (a.track ? AMPS_TRACK_BLOCKS : 0);   // + the most the sampling instants can move
     uint64_t next_allowed = a.next_allowed[c];                        // uniform across the block
     uint64_t pend = a.pending[c];
     auto centre = [](uint64_t ei) -> uint64_t { return (ei >> 8) + (uint32_t)(ei & 0xff) / 2; };   // of the run of matching phases

@@ -140,15 +140,28 @@ def symbol_stream(n_symbols, bursts, rng, idle="random"):
     return s
 
 
-def fsk_modulate(n_samples, bursts, sps=10, fs=200e3, dev=8e3, snr_db=30.0, rng=None, dtype=np.complex64):
+def symbol_waveform(sym, sps, sym_ppm=0.0):
+    """+-1 symbol values held for sps / (1 + sym_ppm 1e-6) samples each: a mobile whose bit clock runs sym_ppm parts per million
+    fast (TIA-553 allows 10 kbit/s +- 1 bit/s = +-100 ppm).  sym_ppm = 0 is np.repeat(sym, sps)."""
+    if sym_ppm == 0.0:
+        return np.repeat(sym, sps)
+    rate = (1.0 + sym_ppm * 1e-6) / sps                       # symbols per sample
+    n = int(np.floor(len(sym) / rate))
+    idx = np.minimum((np.arange(n) * rate).astype(np.int64), len(sym) - 1)
+    return np.asarray(sym)[idx]
+
+
+def fsk_modulate(n_samples, bursts, sps=10, fs=200e3, dev=8e3, snr_db=30.0, rng=None, dtype=np.complex64, sym_ppm=0.0, cfo_hz=0.0):
     """Complex baseband: carrier only during a burst (unit amplitude CPFSK, symbol 1 -> +dev,
-    symbol 0 -> -dev), AWGN everywhere.  `bursts` = [(sample_offset, bits)]."""
+    symbol 0 -> -dev), AWGN everywhere.  `bursts` = [(sample_offset, bits)].  Impairments of the mobile: sym_ppm = symbol-clock
+    offset in parts per million, cfo_hz = carrier offset (both apply to every burst; the defaults draw exactly the samples
+    the unimpaired generator always drew)."""
     rng = rng or np.random.default_rng(0)
     sigma = 10.0 ** (-snr_db / 20.0) / np.sqrt(2.0)
     x = (rng.standard_normal(n_samples) + 1j * rng.standard_normal(n_samples)) * sigma
     for off, bits in bursts:
         sym = manchester(bits).astype(np.float64) * 2.0 - 1.0
-        f = np.repeat(sym, sps) * dev
+        f = symbol_waveform(sym, sps, sym_ppm) * dev + cfo_hz
         n = min(f.size, n_samples - off)
         if n <= 0:
             continue
@@ -157,7 +170,7 @@ def fsk_modulate(n_samples, bursts, sps=10, fs=200e3, dev=8e3, snr_db=30.0, rng=
     return x.astype(dtype)
 
 
-def make_channel_block(n_samples, n_bursts, seed, sps=10, snr_db=30.0, first=4000, spacing=None, jitter=True):
+def make_channel_block(n_samples, n_bursts, seed, sps=10, snr_db=30.0, first=4000, spacing=None, jitter=True, sym_ppm=0.0, cfo_hz=0.0):
     """One channel of config-1 style input with `n_bursts` random messages; returns (iq, truth)
     where truth = [(sample_offset, kind, min10, esn, dialed, words36)]."""
     rng = np.random.default_rng(seed)
@@ -173,5 +186,5 @@ def make_channel_block(n_samples, n_bursts, seed, sps=10, snr_db=30.0, first=400
         bursts.append((off, bits))
         truth.append((off, kind, min10, esn, dialed, words))
         off += spacing + (int(rng.integers(0, 997)) if jitter else 0)
-    iq = fsk_modulate(n_samples, bursts, sps=sps, fs=20e3 * sps, snr_db=snr_db, rng=rng)
+    iq = fsk_modulate(n_samples, bursts, sps=sps, fs=20e3 * sps, snr_db=snr_db, rng=rng, sym_ppm=sym_ppm, cfo_hz=cfo_hz)
     return iq, truth

@@ -69,6 +69,10 @@ extern "C" {
                                                With no SLICER flag a handle uses amps_recc_default_slicer() */
 #define AMPS_RECC_FLAG_KEEP_BURSTS  0x20u /* IQ / wideband seams: also keep the 3374 captured symbol bytes of every burst (what
                                                gr::amps::recc publishes on "bursts", lib/recc_impl.cc:126) for amps_recc_drain_bursts */
+#define AMPS_RECC_FLAG_FIXED_TIMING 0x100u /* IQ / wideband seams: sample all 3374 symbols of a capture at the one phase the trigger run
+                                               gives (rounds 1-3).  Default: the capture tracks the mobile's bit clock, one sample per
+                                               repeat at most, from where the mid-bit transitions fall -- the fast path's
+                                               stand-in for clock_recovery_mm_ff's loop (grc/recctest.grc:846-874) */
 #define AMPS_RECC_FLAG_MAJORITY     0x2u /* decode mode "majority" instead of "reference" (SURVEY.md 8f.2), see below */
 
 /* message classes, the branches of lib/recc_decode_impl.cc:108-168 */
@@ -284,6 +288,14 @@ int amps_recc_drain_bursts(amps_recc_t *h, amps_recc_burst_t *out, uint8_t *burs
  * channel for the last push_iq() call.  demod/soft/hard are host arrays of length n (may be NULL). */
 int amps_recc_debug_demod(amps_recc_t *h, const float *iq, size_t nsamp, int mem,
                           float *demod, float *soft, uint8_t *hard);
+
+/* test tap of slicer spec D's bit logic, evaluated ON THE HOST by the very functions the kernels inline (no device needed):
+ *   form 0: the streaming kernel's 32-sample window, oldest sample at bit 0: in = {SX, ST, SC}; out[0] = the slicer bits, exact from bit
+ *           `sps` on (sps = any supported samples-per-symbol);
+ *   form 1: the filter bank's word, newest frame at bit 0, 3 frames per symbol: in = {SX, ST, SC, SX of the previous 32 frames, wp and wm
+ *           of the previous call}; out = {slicer bits, wp, wm}.
+ * 0, or -EINVAL. */
+int amps_recc_debug_exact_slice(int form, int sps, const uint32_t *in, uint32_t *out);
 
 /* test tap of the channelizer seam: channelise nsamp wideband samples (continuing the handle's wideband
  * stream) WITHOUT running the RECC kernels; out is host memory [n_channels][out_ld] fc32, *nframes the

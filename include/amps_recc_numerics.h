@@ -93,19 +93,24 @@
  * handle, and the two floats spec D does compute (it, ic) are what its debug taps return.
  *
  * ---- which spec is the default, and what the others cost in sensitivity ----
- * AMPS_SLICER_DEFAULT = spec A.  scripts/slicer_sensitivity.py (profiles/r03/slicer_sensitivity.txt; 1000 bursts per point on the
- * IQ seam, 1248 on the wideband seam, C/N stated in a 30 kHz channel) gives the C/N at which 1 % of the seizure bursts are lost:
+ * AMPS_SLICER_DEFAULT = spec D (round 4; rounds 1-3: spec A).  scripts/slicer_sensitivity.py (profiles/r04/slicer_sensitivity.txt;
+ * 1000 bursts per point on the IQ seam, 1248 on the wideband seam, C/N stated in a 30 kHz channel) gives the C/N at which 1 % of the
+ * seizure bursts are lost:
  *
- *                          spec A     spec B            spec C            restated reference chain (M&M timing)
- *   IQ seam (behind the    10.2 dB    10.1 dB (-0.1)    11.2 dB (+1.0)    24.8 dB  (its loop must lock inside the four spare
- *   flow graph's 299-tap                                                            dotting bits: 3 % of the bursts are lost
- *   channel filter)                                                                 at 20 dB, 0.2 % at 30 dB)
- *   wideband seam           9.6 dB    11.7 dB (+2.0)    13.3 dB (+3.7)    24.1 dB
+ *                          spec A     spec B            spec C            spec D            restated reference chain (M&M timing)
+ *   IQ seam (behind the    10.23 dB   10.10 dB (-0.1)   11.20 dB (+1.0)   10.23 dB (0.00)   24.8 dB  (its loop must lock inside the
+ *   flow graph's 299-tap                                                                             four spare dotting bits)
+ *   channel filter)
+ *   wideband seam           9.64 dB   11.68 dB (+2.0)   13.30 dB (+3.7)    9.64 dB (0.00)   24.3 dB
  *
- * Undetected wrong words (flagged valid, different from what was sent) stay below 1e-3 of the valid words for every spec from
- * 10 dB up.  Spec C saves 27 % of the filter-bank kernel's time and costs 3.7 dB on the wideband seam (three samples per symbol:
- * the amplitude-weighted sine of a 0.84 rad step is a poorer statistic than the angle itself); spec B is free on band-limited
- * input but wraps on white noise (8.1 dB -> 15.0 dB at 200 ksps without a channel filter).  Both stay opt-in.
+ * Spec D's loss column equals spec A's burst for burst (same seeds): it makes the same decisions except within rounding of S = 0.
+ * It costs the filter-bank kernel 0.42 ms per GiB against 0.51-0.53 for spec A (0.40 for B / C), so it is the default: spec A's
+ * sensitivity without the arctangent.  Spec A stays selectable (AMPS_RECC_FLAG_SLICER_ATAN) and is the spec whose FM-demod float
+ * d[n] is held to AMPS_DEMOD_TOL_RAD against libm; specs B and C stay opt-in: C costs 3.7 dB on the wideband seam (three samples
+ * per symbol: the amplitude-weighted sine of a 0.84 rad step is a poorer statistic than the angle itself), B is free on
+ * band-limited input but wraps on white noise (8.1 dB -> 15.0 dB at 200 ksps without a channel filter) and under a carrier offset
+ * (+-2 kHz uses up its whole margin to the wrap).  Undetected wrong words (flagged valid, different from what was sent) stay below
+ * 1e-3 of the valid words for every spec from 10 dB up.
  */
 #ifndef AMPS_RECC_NUMERICS_H
 #define AMPS_RECC_NUMERICS_H
@@ -130,12 +135,14 @@
 #define AMPS_HALO_SAMPLES   1024   /* history recomputed at the head of every chunk / kept per push */
 #define AMPS_WORD_SAMPLES   64     /* samples per packed slicer word                              */
 #define AMPS_DEDUP_SYMBOLS  2      /* trigger hits closer than this many symbols form one run     */
+#define AMPS_TRACK_BLOCKS   36     /* timing-tracking blocks of a burst: the trigger's 37 bits, the coded DCC with the first repeat,
+                                      then 34 repeats of 48 bits; also the most the sampling instants can move (one sample per block) */
 
 /* slicer specs */
-#define AMPS_SLICER_ATAN_BOXCAR 0  /* spec A: discriminator + boxcar (default)                      */
+#define AMPS_SLICER_ATAN_BOXCAR 0  /* spec A: discriminator + boxcar (the default of rounds 1-3)      */
 #define AMPS_SLICER_PRODUCT     1  /* spec B: sign of Im(x[n] conj(x[n-sps]))                        */
 #define AMPS_SLICER_SINE        2  /* spec C: boxcar over Im(x[n] conj(x[n-1])), no arctangent       */
 #define AMPS_SLICER_EXACT       3  /* spec D: sign of spec A's boxcar sum from sign bits and the winding number, no arctangent */
-#define AMPS_SLICER_DEFAULT     AMPS_SLICER_ATAN_BOXCAR  /* what a handle created with no SLICER flag uses (amps_recc_default_slicer) */
+#define AMPS_SLICER_DEFAULT     AMPS_SLICER_EXACT        /* what a handle created with no SLICER flag uses (amps_recc_default_slicer) */
 
 #endif

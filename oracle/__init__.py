@@ -116,6 +116,8 @@ def lib():
     L.orc_fused_set_majority.restype = None
     L.orc_fused_set_slicer.argtypes = [C.c_void_p, C.c_int]
     L.orc_fused_set_slicer.restype = None
+    L.orc_fused_set_tracking.argtypes = [C.c_void_p, C.c_int]
+    L.orc_fused_set_tracking.restype = None
     L.orc_fused_push.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     L.orc_fused_push.restype = C.c_size_t
     L.orc_fused_processed.argtypes = [C.c_void_p]
@@ -363,12 +365,14 @@ def fm_discriminator(iq):
 class Fused:
     """CPU model of the fused MI355X seam for one channel."""
 
-    def __init__(self, channel=0, sps=10, tolerance=0, majority=False, slicer=None):
+    def __init__(self, channel=0, sps=10, tolerance=0, majority=False, slicer=None, tracking=True):
         # slicer: AMPS_SLICER_* of include/amps_recc_numerics.h (0 = A, 1 = B, 2 = C, 3 = D); None = AMPS_SLICER_DEFAULT, what a product
         # handle created with no slicer flag uses
         self._h = lib().orc_fused_new(channel, sps)
         if slicer is not None:
             lib().orc_fused_set_slicer(self._h, int(slicer))
+        if not tracking:
+            lib().orc_fused_set_tracking(self._h, 0)
         if tolerance:
             lib().orc_fused_set_tolerance(self._h, int(tolerance))
         if majority:
@@ -396,12 +400,12 @@ class Fused:
         return d, s, g
 
 
-def fused_push_all(iq_2d, sps=10, block=None, tolerance=0, majority=False, slicer=None):
+def fused_push_all(iq_2d, sps=10, block=None, tolerance=0, majority=False, slicer=None, tracking=True):
     """iq_2d: complex64 [C][N]; pushes every channel (optionally in blocks) and returns all records sorted."""
     iq_2d = np.asarray(iq_2d)
     recs = []
     for c in range(iq_2d.shape[0]):
-        f = Fused(c, sps, tolerance, majority, slicer)
+        f = Fused(c, sps, tolerance, majority, slicer, tracking)
         n = iq_2d.shape[1]
         step = n if not block else block
         for off in range(0, n, step):

@@ -66,6 +66,7 @@ struct orc_fused {
     int      tol;             /* accepted mismatching symbols of the 74 (0 = exact match = reference behaviour) */
     int      majority;        /* decode captures in the product's majority mode (AMPS_RECC_FLAG_MAJORITY)       */
     int      slicer;          /* AMPS_SLICER_* of include/amps_recc_numerics.h                                   */
+    int      track;           /* per-repeat timing tracking in the capture (AMPS_RECC_FLAG_FIXED_TIMING clears it)          */
 };
 
 orc_fused_t *orc_fused_new(uint32_t channel, int sps)
@@ -73,6 +74,7 @@ orc_fused_t *orc_fused_new(uint32_t channel, int sps)
     orc_fused_t *f = (orc_fused_t *)calloc(1, sizeof(*f));
     f->channel = channel; f->sps = sps;
     f->slicer = AMPS_SLICER_DEFAULT;
+    f->track = 1;
     orc_trigger(f->trig);
     return f;
 }
@@ -84,6 +86,7 @@ void orc_fused_free(orc_fused_t *f)
 void orc_fused_set_tolerance(orc_fused_t *f, int k) { f->tol = k < 0 ? 0 : k; }
 void orc_fused_set_majority(orc_fused_t *f, int on) { f->majority = on != 0; }
 void orc_fused_set_slicer(orc_fused_t *f, int spec) { f->slicer = spec; }
+void orc_fused_set_tracking(orc_fused_t *f, int on) { f->track = on != 0; }
 size_t orc_fused_processed(const orc_fused_t *f) { return f->n_done; }
 const float *orc_fused_demod(const orc_fused_t *f) { return f->d; }
 const float *orc_fused_soft(const orc_fused_t *f) { return f->S; }
@@ -113,11 +116,47 @@ static void grow_wraps(orc_fused_t *f)
 
 static inline int gbit(const orc_fused_t *f, int64_t n) { return n < 0 ? 1 : f->g[n]; }
 
+/* Symbol i of a capture is slicer bit nc + sps (i + 1) + delay(block of i).  With timing tracking (the default) the
+ * burst is walked in 36 blocks -- the 37 bits of the trigger itself (measured only: they lie in front of the capture), then the
+ * coded DCC together with the first repeat (55 bits), then the other 34 repeats of 48 bits -- and after each block the sampling
+ * instants of everything behind it move by one sample if the mid-bit transitions of that block sat, on average, more than half a
+ * sample late or early.  For a Manchester pair (a, b), a != b, sampled at t and t + sps the boxcar output changes sign half way
+ * between, so the number of slicer bits equal to a among t+1 .. t+sps-1 says where the transition really was: e = cnt - (sps-1)/2
+ * samples late.  A carrier offset moves the falling transitions one way and the rising ones the other, so the two polarities are
+ * averaged separately and a block with only one of them measures nothing:
+ *     move by +1 if mean(e | a = 1) + mean(e | a = 0) >  1,   by -1 if < -1        (integers: E1 n0 + E0 n1 vs 2 n0 n1, E = sum 2e)
+ * A first-order timing loop on hard decisions, one step per 96 symbols: it follows a mobile whose bit clock is off by up to
+ * ~1/(96 sps) (3400 ppm at 3 samples per symbol, 1000 ppm at 10; TIA-553 allows 100) and never moves on an exact clock. */
 static void capture(orc_fused_t *f, uint64_t nc, amps_recc_burst_t *out)
 {
     uint8_t burst[AMPS_RECC_CAPTURE_SYMS];
-    for (int i = 0; i < AMPS_RECC_CAPTURE_SYMS; i++) burst[i] = f->g[nc + (uint64_t)f->sps * (uint64_t)(i + 1)];
+    const int sps = f->sps;
+    int dly = 0, k0 = -(AMPS_RECC_TRIGGER_SYMS / 2);          /* bit index relative to the capture: the trigger is bits -37 .. -1 */
+    for (int b = 0; b < AMPS_TRACK_BLOCKS; b++) {
+        const int nb = b == 0 ? AMPS_RECC_TRIGGER_SYMS / 2 : b == 1 ? 7 + AMPS_RECC_WORD_BITS : AMPS_RECC_WORD_BITS;
+        int E[2] = { 0, 0 }, n[2] = { 0, 0 };
+        for (int k = k0; k < k0 + nb; k++) {
+            const uint64_t ta = (uint64_t)((int64_t)nc + (int64_t)sps * (2 * k + 1) + dly);
+            const int a = f->g[ta], bb = f->g[ta + sps];
+            if (k >= 0) { burst[2 * k] = (uint8_t)a; burst[2 * k + 1] = (uint8_t)bb; }
+            if (f->track && a != bb) {
+                int cnt = 0;
+                for (int m = 1; m < sps; m++) cnt += f->g[ta + m] == a;
+                E[a] += 2 * cnt - (sps - 1);
+                n[a]++;
+            }
+        }
+        const int lhs = E[1] * n[0] + E[0] * n[1], rhs = 2 * n[0] * n[1];
+        if (rhs > 0) { if (lhs > rhs) dly++; else if (lhs < -rhs) dly--; }
+        k0 += nb;
+    }
     orc_decode_burst_mode(burst, f->channel, nc, out, f->majority);
+}
+/* samples that must follow n_c before its capture is taken: one symbol more than the capture (the reference's strict '>',
+ * lib/recc_impl.cc:125), plus -- with tracking -- the most the sampling instants can have moved */
+static uint64_t span_done(const orc_fused_t *f)
+{
+    return (uint64_t)f->sps * (AMPS_RECC_CAPTURE_SYMS + 1) + (f->track ? AMPS_TRACK_BLOCKS : 0);
 }
 
 size_t orc_fused_push(orc_fused_t *f, const float *iq, size_t n, amps_recc_burst_t *out, size_t cap)
@@ -199,7 +238,7 @@ size_t orc_fused_push(orc_fused_t *f, const float *iq, size_t n, amps_recc_burst
     /* run starts located in word w are examined when word w+1 has been processed */
     int64_t w_lo = (int64_t)(lo / AMPS_WORD_SAMPLES) - 1, w_hi = (int64_t)(hi / AMPS_WORD_SAMPLES) - 1;
     /* previously accepted burst waiting for its tail */
-    if (f->have_pending && f->pending_nc + (uint64_t)sps * (AMPS_RECC_CAPTURE_SYMS + 1) < hi) {
+    if (f->have_pending && f->pending_nc + span_done(f) < hi) {
         if (nout < cap) capture(f, f->pending_nc, &out[nout++]);
         f->have_pending = 0;
     }
@@ -216,7 +255,7 @@ size_t orc_fused_push(orc_fused_t *f, const float *iq, size_t n, amps_recc_burst
             if (a < f->next_allowed) continue;
             uint64_t nc = a + (uint64_t)(last / 2);
             f->next_allowed = nc + (uint64_t)sps * (AMPS_RECC_CAPTURE_SYMS + AMPS_RECC_TRIGGER_SYMS);
-            if (nc + (uint64_t)sps * (AMPS_RECC_CAPTURE_SYMS + 1) < hi) {
+            if (nc + span_done(f) < hi) {
                 if (nout < cap) capture(f, nc, &out[nout++]);
             } else {
                 f->have_pending = 1; f->pending_nc = nc;

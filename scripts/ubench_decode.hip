@@ -21,19 +21,19 @@ __global__ __launch_bounds__(256, 4) void k_decode(const uint64_t *ring, uint32_
     extern __shared__ uint64_t s_cap[];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (wv >= nwaves) return;
-    const uint32_t cap_words = (AMPS_RECC_CAPTURE_SYMS * sps) / 64 + 3;
+    const uint32_t cap_words = resolve_cap_words(sps);
     uint64_t *scratch = s_cap + (size_t)wv * resolve_cap_stride(cap_words);
     DecodeCore &k = *(DecodeCore *)scratch;
     uint64_t *s_ring = scratch + (sizeof(DecodeCore) + 7) / 8;
     Stamps st;
     for (int i = 0; i < 10; i++) st.t[i] = 0;
     st.mark(8);
-    const uint64_t nc = 64, w0 = (nc + sps) >> 6;
-    const int nw = (int)(((nc + (uint64_t)sps * AMPS_RECC_CAPTURE_SYMS) >> 6) - w0) + 1;
+    const uint64_t nc = 512, w0 = capture_first_word(nc, sps);
+    const int nw = (int)(((nc + (uint64_t)sps * (AMPS_RECC_CAPTURE_SYMS + 1) + AMPS_TRACK_BLOCKS + 32) >> 6) - w0) + 1;
     for (int i = lane; i < nw; i += 64) s_ring[i] = ring[(size_t)blockIdx.x * ring_words + w0 + i];
     WaveSync::sync();
     st.mark(9);
-    manchester_from_ring<WaveSync>(k, s_ring, nc, w0, sps, lane);
+    manchester_from_ring<WaveSync>(k, s_ring, nc, w0, sps, lane, true);
     st.mark(0);
     StampRef ref{ &st };
     decode_core_wave<WaveSync>(k, blockIdx.x, nc, out + blockIdx.x * 4 + wv, false, lane, ref);

@@ -84,3 +84,69 @@ def test_exact_slicer_model_is_push_invariant(blocks):
     got = np.concatenate(got)
     assert got.tobytes() == ref.tobytes()
     assert np.array_equal(f.taps()[2], one.taps()[2][:len(f.taps()[2])])
+
+
+# ---- the kernels' own bit logic, evaluated on the host through the C ABI (amps_recc_debug_exact_slice): no device needed
+def _spec_d_bits(sx, st, sc, sps):
+    """per-sample statement of include/amps_recc_numerics.h spec D on sign-bit arrays (index = time); positions < sps are don't-care"""
+    n = len(sx)
+    wp = np.zeros(n, int)
+    wm = np.zeros(n, int)
+    g = np.zeros(n, np.uint8)
+    for i in range(n):
+        s1 = sx[i - 1] if i >= 1 else 0
+        wp[i] = (not sx[i]) and s1 and st[i]
+        wm[i] = sx[i] and (not s1) and (not st[i])
+        if i >= sps:
+            ss = sx[i - sps]
+            K = int((not sx[i]) and ss and sc[i]) - int(sx[i] and (not ss) and (not sc[i])) + int(wm[i - sps + 1:i + 1].sum()) - int(wp[i - sps + 1:i + 1].sum())
+            g[i] = K > 0 or (K == 0 and not sc[i])
+    return g, wp, wm
+
+
+@pytest.mark.parametrize("sps", [3, 4, 5, 6, 8, 10, 12])
+def test_streaming_kernels_window_logic_on_the_host(sps):
+    import ctypes as C
+    from gr_amps_amd import capi
+    L = capi.load()
+    L.amps_recc_debug_exact_slice.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    rng = np.random.default_rng(sps)
+    for trial in range(300):
+        # random sign words, with a bias towards long runs (real signals) in half of the trials
+        if trial % 2:
+            bits = [np.repeat(rng.integers(0, 2, 8), 4)[:32] ^ (rng.random(32) < 0.1) for _ in range(3)]
+        else:
+            bits = [rng.integers(0, 2, 32) for _ in range(3)]
+        sx, st, sc = (np.asarray(b, int) for b in bits)
+        words = (C.c_uint32 * 3)(*[int(sum(int(b[i]) << i for i in range(32))) for b in (sx, st, sc)])   # oldest sample at bit 0
+        out = (C.c_uint32 * 3)()
+        assert L.amps_recc_debug_exact_slice(0, sps, words, out) == 0
+        g, _, _ = _spec_d_bits(sx, st, sc, sps)
+        got = np.array([(out[0] >> i) & 1 for i in range(32)], np.uint8)
+        assert np.array_equal(got[sps + 1:], g[sps + 1:]), (trial, sps)
+    assert L.amps_recc_debug_exact_slice(0, 7, words, out) != 0          # unsupported samples per symbol
+
+
+def test_filter_bank_word_logic_on_the_host():
+    """the filter bank's form: newest frame at bit 0, the previous 32 frames in a second word, wrap words carried from call to call"""
+    import ctypes as C
+    from gr_amps_amd import capi
+    L = capi.load()
+    L.amps_recc_debug_exact_slice.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    rng = np.random.default_rng(33)
+    n = 32 * 40
+    sx, st, sc = (rng.integers(0, 2, n) for _ in range(3))
+    g, wp, wm = _spec_d_bits(sx, st, sc, 3)
+
+    def word(b, w):       # frames [32 w, 32 w + 32), newest at bit 0
+        return int(sum(int(b[32 * w + 31 - i]) << i for i in range(32))) if w >= 0 else 0
+    prev = [0, 0, 0]      # SX, wp, wm of the previous 32 frames
+    for w in range(n // 32):
+        inp = (C.c_uint32 * 6)(word(sx, w), word(st, w), word(sc, w), prev[0], prev[1], prev[2])
+        out = (C.c_uint32 * 3)()
+        assert L.amps_recc_debug_exact_slice(1, 3, inp, out) == 0
+        lo = 3 if w == 0 else 0
+        got = np.array([(out[0] >> (31 - i)) & 1 for i in range(32)], np.uint8)
+        assert np.array_equal(got[lo:], g[32 * w + lo:32 * w + 32]), w
+        assert out[1] == word(wp, w) and out[2] == word(wm, w)
+        prev = [word(sx, w), out[1], out[2]]

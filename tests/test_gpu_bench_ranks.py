@@ -40,6 +40,12 @@ def test_two_ranks_whole_bands(gpu):
     c = d["config"]
     assert c["channels_per_gpu"] == 832 and c["checked"]["decoded_with_transmitted_MIN"] >= 0.97 * c["checked"]["planted"] > 0
     assert abs(d["value"] - 2 * 832 * ((1 << 24) / 1536.0) * 3 / (d["ms_per_step"] * 3e-3) * 1e-6) < 1e-3 * d["value"]
+    # the same invocation also measures what BASELINE configs[4] names: one band, rank 0's block broadcast inside the timed region
+    s = d["secondary"]
+    assert s["scaling"] == "strong" and s["collective"]["nranks"] == 2 and s["collective"]["bytes_per_step"] == 8 << 24
+    assert len(s["kernel_ms_per_rank"]) == 2 and all(k > 0 for k in s["kernel_ms_per_rank"])
+    assert s["config"]["channels_per_gpu"] == 416 and s["config"]["checked"]["decoded_with_transmitted_MIN"] >= 0.97 * s["config"]["checked"]["planted"] > 0
+    assert abs(s["value"] - 832 * ((1 << 24) / 1536.0) * s["steps"] / (s["ms_per_step"] * s["steps"] * 1e-3) * 1e-6) < 1e-3 * s["value"]
 
 
 def test_two_ranks_one_band_by_channel_groups(gpu):

@@ -211,11 +211,13 @@ def test_fused_iq_ragged_pushes(gpu, blocks):
 
 
 def test_fm_demod_intermediates_within_tolerance(gpu):
+    """the FM-demod float intermediate exists under slicer spec A (the arctangent discriminator); the default since round 4, spec D,
+    makes the same decisions without materialising it (tests/test_gpu_slicer_specs.py holds its bits to the float64 libm sign)"""
     iq, _ = _channels(1, 50000, 400, nb=1)
     x = iq[0]
-    with capi.Recc(n_channels=1, sps=10, max_samples=65536, max_bursts=8) as r:
+    with capi.Recc(n_channels=1, sps=10, max_samples=65536, max_bursts=8, slicer="atan") as r:
         d, s, g = r.debug_demod(x)
-    f = oracle.Fused(0, 10)
+    f = oracle.Fused(0, 10, slicer=0)
     f.push(x)
     md, ms, mg = f.taps()
     n = len(d)

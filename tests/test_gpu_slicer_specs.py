@@ -165,7 +165,8 @@ def test_round2_golden_fixture_on_the_device(gpu):
             with capi.Recc(n_channels=1, sps=10, max_samples=65536, max_bursts=16, slicer=name) as r:
                 r.push_iq(x[None, :])
                 assert r.drain().view(np.uint8).tobytes() == g2["iq_records_" + name].tobytes()
-        with capi.Recc(n_channels=2, sps=10, max_samples=xn.shape[1], max_bursts=16, slicer=name) as r:
+        # the round-2 records were taken at one fixed phase per capture; the tracking default is pinned by recc_golden_r04.npz
+        with capi.Recc(n_channels=2, sps=10, max_samples=xn.shape[1], max_bursts=16, slicer=name, fixed_timing=True) as r:
             r.push_iq(xn)
             assert r.drain().view(np.uint8).tobytes() == g2["noisy_records_" + name].tobytes()
         for c in range(2):
@@ -173,3 +174,23 @@ def test_round2_golden_fixture_on_the_device(gpu):
                 bits = r.debug_demod(xn[c])[2]
             assert hashlib.sha256(bits.tobytes()).hexdigest() == str(g2["noisy_bits_sha_" + name][c]), (name, c)
 
+
+
+@pytest.mark.parametrize("sps,snr", [(3, 30.0), (3, 6.0), (10, 30.0), (10, 3.0), (12, 0.0)])
+def test_exact_slicer_is_the_sign_of_the_libm_boxcar_on_the_device(gpu, sps, snr):
+    """spec D's claim, checked on the device against an independent float64 statement: its bit is (sum of the last sps libm atan2
+    phase steps >= 0) wherever that sum is more than 1e-4 rad away from zero -- no arctangent is evaluated on the device"""
+    iq, _ = _channels(1, 3456 * sps + 20000, 990 + sps, nb=1, snr=snr, sps=sps)
+    x = iq[0]
+    with capi.Recc(n_channels=1, sps=sps, max_samples=65536, max_bursts=8, slicer="exact") as r:
+        g = r.debug_demod(x[:65536])[2]
+    n = len(g)
+    xc = x[:n].astype(np.complex128)
+    t = xc * np.conj(np.concatenate([[0], xc[:-1]]))
+    d = np.where(t == 0, 0.0, np.angle(t))
+    cs = np.concatenate([[0.0], np.cumsum(d)])
+    idx = np.arange(n)
+    S = cs[idx + 1] - cs[np.maximum(idx - sps + 1, 0)]
+    diff = np.nonzero(g[sps:] != (S[sps:] >= 0))[0] + sps
+    assert len(diff) <= 2 and (np.abs(S[diff]) <= 1.0e-4).all(), (len(diff), np.abs(S[diff]).max() if len(diff) else 0.0)
+    assert (np.abs(S) > np.pi).any() or snr > 10.0          # the noisy cases leave (-pi, pi]: the winding number is exercised
