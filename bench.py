@@ -57,7 +57,11 @@ def parse(argv=None):
                          "uses (amps_recc_default_slicer(): spec D, the sign of the arctangent discriminator's boxcar sum computed exactly from sign "
                          "bits and the winding number) -- the headline is the product's default path; atan = spec A (the arctangent itself, default of "
                          "rounds 1-3), sine = spec C, product = spec B: opt-in variants, their kernel times are reported under 'other_slicer_specs'")
-    ap.add_argument("--dist", default="bands", choices=["bands", "broadcast", "scatter_allgather"])
+    ap.add_argument("--dist", default="bands", choices=["bands", "broadcast", "scatter_allgather", "broadcast_abi"],
+                    help="bands (default): one 832-channel band per GPU, no data-path collective.  broadcast / scatter_allgather: ONE band, rank 0's block "
+                         "distributed every step through torch.distributed (RCCL), channel groups per rank.  broadcast_abi: the same broadcast issued by the "
+                         "library itself (amps_recc_push_wideband_bcast: ncclBroadcast on the library's own stream; torch.distributed only carries the "
+                         "128-byte communicator id)")
     ap.add_argument("--groups", type=int, default=0, choices=[0, 2, 4, 8],
                     help="N = 1 only: run wideband832 as ONE rank of the one-band split over that many GPUs (cfg.wideband_groups: the rank decodes one "
                          "interleaved channel group and skips the last FFT pass and the slicer for the others' bins) -- the per-rank kernel time of --dist broadcast")
@@ -327,17 +331,23 @@ def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, w
             planted = {c - rank * C: m for c, m in planted.items() if rank * C <= c < (rank + 1) * C}
         else:
             batch, planted = make_wideband_batch(torch, dev, NW, first_bin, C, 2, seed=rank + 1)
-        if one_band:
+        if one_band and dist_mode != "broadcast_abi":
             recv = [torch.empty_like(batch), torch.empty_like(batch)]
         expected = len(planted)
         iq_base = None
         r = capi.Recc(n_channels=n_band, sps=sps, max_samples=N + 8, max_bursts=max(4096, 2 * expected), device=local, time_kernels=True,
                       slicer=slicer, sync_torch=False, wideband=wb)
+        if one_band and dist_mode == "broadcast_abi":     # the communicator lives in the handle; the id travels over the control plane
+            ids = [capi.Recc.rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            r.rccl_init(ids[0], world, rank)
         step_no = [0]
         busy = [None, None]                               # per receive buffer: event behind the kernels that last read it
 
         def push():
-            if one_band:
+            if one_band and dist_mode == "broadcast_abi":
+                r.push_wideband_bcast(batch if rank == 0 else None, NW, 0)
+            elif one_band:
                 # the step's block travels rank 0 -> everybody over xGMI inside the timed region; two receive buffers, so the
                 # collective of step i overlaps the kernels of step i - 1 and only waits for those of step i - 2
                 slot = step_no[0] & 1
@@ -469,7 +479,7 @@ def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, w
     if wide and groups in (2, 4, 8):
         par = ("one band, %d interleaved channel groups (cfg.wideband_groups), this line = group %d: %d channels; every rank folds the whole stream, "
                "pass 3 of the FFT and the slicer run for the rank's own bins only%s"
-               % (groups, group, C, ("; rank 0's block by RCCL %s every step" % ("broadcast" if dist_mode == "broadcast" else "scatter + all-gather")) if one_band else
+               % (groups, group, C, ("; rank 0's block by RCCL %s every step" % ({"broadcast": "broadcast", "broadcast_abi": "broadcast issued inside the C ABI"}.get(dist_mode, "scatter + all-gather"))) if one_band else
                   " (single-GPU measurement of one rank's share, --groups)"))
     elif one_band:
         par = ("%s: rank 0's block by RCCL %s every step, rank r decodes channels [%d r, %d (r+1)); the whole filter bank runs on every rank"

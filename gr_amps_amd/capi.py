@@ -98,6 +98,7 @@ EXPORTS = (
     "amps_recc_drain_begin", "amps_recc_drain_end", "amps_recc_set_origin",
     "amps_recc_wait_event", "amps_recc_record_event", "amps_recc_refchain_symbols", "amps_recc_refchain_tables",
     "amps_recc_drain_bursts", "amps_recc_default_slicer", "amps_recc_debug_exact_slice",
+    "amps_recc_rccl_unique_id", "amps_recc_rccl_init", "amps_recc_push_wideband_bcast",
 )
 
 _lib = None
@@ -135,6 +136,10 @@ def load():
     L.amps_recc_decode_bursts.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, vp]
     L.amps_recc_push_iq.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int]
     L.amps_recc_push_wideband.argtypes = [vp, vp, C.c_size_t, C.c_int]
+    if hasattr(L, "amps_recc_push_wideband_bcast"):   # absent only from A/B builds of earlier revisions (AMPS_RECC_LIB)
+        L.amps_recc_rccl_unique_id.argtypes = [vp]
+        L.amps_recc_rccl_init.argtypes = [vp, vp, C.c_int, C.c_int]
+        L.amps_recc_push_wideband_bcast.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int]
     L.amps_recc_drain.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.amps_recc_refchain_symbols.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, vp, C.c_size_t, vp]
     L.amps_recc_refchain_tables.argtypes = [vp, vp, vp]
@@ -154,7 +159,8 @@ def load():
     L.amps_bch_encode_words.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, vp]
     L.amps_bch_decode_words.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, vp, vp, vp]
     for name in EXPORTS:
-        if name == "amps_recc_default_slicer" and not hasattr(L, name):
+        if name in ("amps_recc_default_slicer", "amps_recc_debug_exact_slice", "amps_recc_rccl_unique_id", "amps_recc_rccl_init",
+                    "amps_recc_push_wideband_bcast") and not hasattr(L, name):
             continue
         if name not in ("amps_recc_strerror", "amps_recc_burst_size", "amps_recc_destroy"):   # every other entry point returns int
             getattr(L, name).restype = C.c_int
@@ -333,6 +339,34 @@ class Recc:
         rc = load().amps_recc_push_wideband(self._h, ptr, n, mem)
         if rc:
             raise AmpsError(rc, "amps_recc_push_wideband")
+
+    # ---- one band over the GPUs of a node: RCCL inside the C ABI (include/amps_recc.h, amps_recc_push_wideband_bcast)
+    @staticmethod
+    def rccl_unique_id():
+        """128 bytes from ncclGetUniqueId: one rank makes them, the application carries them to the others"""
+        buf = (C.c_uint8 * 128)()
+        rc = load().amps_recc_rccl_unique_id(buf)
+        if rc:
+            raise AmpsError(rc, "amps_recc_rccl_unique_id")
+        return bytes(buf)
+
+    def rccl_init(self, uid, nranks, rank):
+        """collective: returns when all nranks handles (one per GPU / process) have joined"""
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        rc = load().amps_recc_rccl_init(self._h, buf, int(nranks), int(rank))
+        if rc:
+            raise AmpsError(rc, "amps_recc_rccl_init")
+
+    def push_wideband_bcast(self, iq, nsamp, root=0):
+        """every rank in step; the root passes its block (a CUDA tensor, used in place, or a numpy array, staged), the others None"""
+        ptr, mem = None, MEM_DEVICE
+        if iq is not None:
+            if isinstance(iq, np.ndarray):
+                iq = np.ascontiguousarray(iq, np.complex64).reshape(-1)
+            ptr, mem, keep = _as_ptr(iq, self.sync_torch)
+        rc = load().amps_recc_push_wideband_bcast(self._h, ptr, int(nsamp), mem, int(root))
+        if rc:
+            raise AmpsError(rc, "amps_recc_push_wideband_bcast")
 
     def refchain_symbols(self, iq):
         """The flow graph's own sub-chain (quadrature_demod_cf -> clock_recovery_mm_ff -> binary_slicer_fb) on the device:

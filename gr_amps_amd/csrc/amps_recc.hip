@@ -17,6 +17,7 @@
 #include "recc_resolve.hip.h"
 #include "recc_symbols.hip.h"
 #include "recc_channelizer.hip.h"
+#include "recc_rccl.hip.h"
 #include "recc_xlate.hip.h"
 #include "recc_bits.hip.h"
 #include "recc_refchain.hip.h"
@@ -56,6 +57,7 @@ struct amps_recc {
     uint64_t n_done = 0;
     uint64_t origin = 0;              // absolute index of the stream's first sample (amps_recc_set_origin)
     int slicer = AMPS_SLICER_DEFAULT;       // numeric spec of the slicer (AMPS_RECC_FLAG_SLICER_* select one explicitly)
+    RcclState rccl;                         // one band over several GPUs: amps_recc_rccl_init / amps_recc_push_wideband_bcast
     uint32_t r_prev = 0;
     bool origin_locked = false;       // a push has happened since the last reset
     uint64_t *gring = nullptr;
@@ -370,7 +372,13 @@ static void launch_resolve(amps_recc *h, ResolveArgs &ra, hipStream_t s)
     if (!tl_dev) (void)hipMalloc((void **)&tl_dev, (size_t)24 * 8 * 4096);
     if (tl_dev && h->C <= 4096) { (void)hipMemsetAsync(tl_dev, 0, (size_t)24 * 8 * h->C, s); ra.tl = tl_dev; }
 #endif
-    if (ra.tiles_per_channel / ra.span + 2 > (uint64_t)RESOLVE_THREADS)
+    // The wide instantiation (a channel cut into more wave segments than 256 lanes compact in one batch) exists for handles with few
+    // channels, which always take the queue form: its 36.9 KB of static LDS next to the fused capture form's dynamic LDS is a
+    // combination max_chunks never produces for 64 channels or more (Tc / span + 2 <= max_waves / C + 4 <= 131 there).  Held here, so
+    // that a change to either threshold cannot turn into a launch failure: a handle without a queue stays on the narrow kernel, whose
+    // batches walk any number of segments.
+    const bool wide = ra.tiles_per_channel / ra.span + 2 > (uint64_t)RESOLVE_THREADS && h->capq != nullptr;
+    if (wide)
         hipLaunchKernelGGL((recc_resolve_kernel<RESOLVE_THREADS_WIDE, RESOLVE_LDS_HITS_WIDE>), dim3(h->C), dim3(RESOLVE_THREADS_WIDE), lds, s, ra);
     else
         hipLaunchKernelGGL((recc_resolve_kernel<RESOLVE_THREADS, RESOLVE_LDS_HITS>), dim3(h->C), dim3(RESOLVE_THREADS), lds, s, ra);
@@ -602,6 +610,7 @@ void amps_recc_destroy(amps_recc_t *h)
     for (int b = 0; b < 2; b++) if (h->bsym_host_buf[b]) (void)hipHostFree(h->bsym_host_buf[b]);
     if (h->drain_event) (void)hipEventDestroy(h->drain_event);
     if (h->hdr_host) (void)hipHostFree(h->hdr_host);
+    rccl_destroy(h->rccl);
     channelizer_destroy(h->chz);
     xlate_destroy(h->xl);
     ref_destroy(h->ref);
@@ -623,6 +632,7 @@ int amps_recc_push_symbols(amps_recc_t *h, const uint8_t *syms, size_t ld, int n
 {
     if (!h || !nout) return -EINVAL;
     *nout = 0;
+    if (h->chz.enabled && h->chz.groups > 1) return -ENOSYS;   // a channel-group handle owns its group's rows of the wideband seam only
     if (n < 1) return 0;                                   // lib/recc_impl.cc:99-102
     if (n > AMPS_RECC_MAX_WORK_ITEMS) return -EINVAL;      // lib/recc_impl.cc:103
     if (!syms || ld < (size_t)n) return -EINVAL;
@@ -712,6 +722,8 @@ int amps_recc_push_iq(amps_recc_t *h, const float *iq, size_t ld, size_t nsamp, 
 {
     if (!h) return -EINVAL;
     if (!h->carry[0]) return -ENOSYS;
+    if (h->chz.enabled && h->chz.groups > 1) return -ENOSYS;   // a channel-group handle owns its group's rows of the wideband seam only: its
+                                                               // records are numbered through row2chan, which means nothing on this seam
     if (nsamp == 0) return 0;
     if (!iq || ld < nsamp) return -EINVAL;
     if (nsamp > h->cfg.max_samples_per_push) return -E2BIG;
@@ -815,6 +827,39 @@ int amps_recc_push_wideband(amps_recc_t *h, const float *iq, size_t nsamp, int m
     return run_iq_device(h, chan_iq, ld, nout);
 }
 
+int amps_recc_rccl_unique_id(uint8_t *id)
+{
+    if (!id) return -EINVAL;
+    RcclApi &api = rccl_api();
+    if (!api.ok()) return -ENOSYS;
+    RcclId uid;
+    if (api.GetUniqueId(&uid) != 0) return -EIO;
+    std::memcpy(id, uid.internal, sizeof(uid.internal));
+    return 0;
+}
+
+int amps_recc_rccl_init(amps_recc_t *h, const uint8_t *id, int nranks, int rank)
+{
+    if (!h) return -EINVAL;
+    if (!h->chz.enabled) return -ENOSYS;
+    HIP_TRY(hipSetDevice(h->device));
+    return rccl_init(h->rccl, id, nranks, rank);
+}
+
+int amps_recc_push_wideband_bcast(amps_recc_t *h, const float *iq, size_t nsamp, int mem, int root)
+{
+    if (!h) return -EINVAL;
+    if (!h->chz.enabled || !h->rccl.comm) return -ENOSYS;
+    if (nsamp == 0) return -EINVAL;                           // a collective: every rank must issue the same, non-empty, broadcast
+    HIP_TRY(hipSetDevice(h->device));
+    const float2 *blk = nullptr;
+    int slot = 0;
+    if (int rc = rccl_broadcast_block(h->rccl, (const float2 *)iq, mem == AMPS_MEM_HOST, nsamp, root, h->stream, &blk, &slot)) return rc;
+    const int rc = amps_recc_push_wideband(h, (const float *)blk, nsamp, AMPS_MEM_DEVICE);
+    const int rc2 = rccl_block_consumed(h->rccl, slot, h->stream);
+    return rc ? rc : rc2;
+}
+
 int amps_recc_set_xlate(amps_recc_t *h, const amps_recc_xlate_cfg_t *x)
 {
     if (!h || !x || x->struct_size != sizeof(amps_recc_xlate_cfg_t)) return -EINVAL;
@@ -838,6 +883,7 @@ int amps_recc_push_raw(amps_recc_t *h, const float *iq, size_t ld, size_t nsamp,
 {
     if (!h) return -EINVAL;
     if (!h->xl.enabled) return -ENOSYS;
+    if (h->chz.enabled && h->chz.groups > 1) return -ENOSYS;
     if (nsamp == 0) return 0;
     if (!iq || ld < nsamp) return -EINVAL;
     HIP_TRY(hipSetDevice(h->device));
@@ -966,19 +1012,22 @@ static int drain_end_impl(amps_recc_t *h, amps_recc_burst_t *out, uint8_t *burst
     if (!h || !nout) return -EINVAL;
     *nout = 0;
     if (h->open_buf < 0) return -EINVAL;
-    HIP_TRY(hipSetDevice(h->device));
     const int b = h->open_buf;
-    HIP_TRY(hipEventSynchronize(h->drain_event));   // everything enqueued before drain_begin is done; later pushes may still run
-    collect_spans(h);
     volatile uint32_t *hdr = h->hdr_host + HDR_STRIDE * b;
+    // an error below still CLOSES the split drain (and empties the list's header): a handle must not answer -EBUSY for ever
+    // because one drain failed
+    auto fail = [&](int rc) { hdr[0] = 0u; hdr[1] = 0u; h->open_buf = -1; return rc; };
+    if (hipSetDevice(h->device) != hipSuccess) return fail(-EIO);
+    if (hipEventSynchronize(h->drain_event) != hipSuccess) return fail(-EIO);   // everything enqueued before drain_begin is done; later pushes may still run
+    collect_spans(h);
     uint32_t n = hdr[0];
     const uint32_t st = hdr[1];
     if (check_header_enabled() && h->open_untouched) {
         uint32_t dev[2] = { 0u, 0u };
-        HIP_TRY(hipMemcpy(dev, h->nrecords_buf[b], sizeof(dev), hipMemcpyDeviceToHost));
+        if (hipMemcpy(dev, h->nrecords_buf[b], sizeof(dev), hipMemcpyDeviceToHost) != hipSuccess) return fail(-EIO);
         if (dev[0] != n || dev[1] != st) {
             std::fprintf(stderr, "amps_recc: published list header {%u, %u} differs from the device counters {%u, %u}\n", n, st, dev[0], dev[1]);
-            return -EIO;
+            return fail(-EIO);
         }
     }
     hdr[0] = 0u; hdr[1] = 0u;               // empty until a capture kernel publishes into it again (the list is not current now)

@@ -106,7 +106,7 @@ int main(int argc, char **argv)
                 if (src->work(n, ins, outs) != 0) return 1;
             }
         } else if (mode == "wide") {
-            auto src = gr::amps::recc_wideband::make(832, 96, argc > 4 ? std::atoi(argv[4]) : 0);
+            auto src = gr::amps::recc_wideband::make(832, 96, argc > 4 ? std::atoi(argv[4]) : -1);
             struct demux : gr::block {
                 std::shared_ptr<gr::basic_block> dec;
                 demux() : gr::block("demux", gr::io_signature::make(0, 0, 0), gr::io_signature::make(0, 0, 0))

@@ -8,6 +8,7 @@
 // channel 0 = FFT bin `first_bin` (centre first_bin x 30 kHz above the stream's centre, modulo the sample rate).
 #pragma once
 #include <amps/api.h>
+#include <string>
 
 namespace gr {
 namespace amps {
@@ -15,8 +16,18 @@ namespace amps {
 class AMPS_API recc_wideband : virtual public gr::sync_block {
 public:
     typedef AMPS_SPTR<recc_wideband> sptr;
-    // slicer: 0 = numeric spec A (discriminator + boxcar), 1 = spec B, 2 = spec C (include/amps_recc_numerics.h)
-    static sptr make(int n_channels = 832, int first_bin = 96, int slicer = 0);
+    // slicer: -1 = the library default (spec D since round 4), 0 = numeric spec A (arctangent discriminator + boxcar), 1 = spec B,
+    //         2 = spec C, 3 = spec D (include/amps_recc_numerics.h)
+    // groups / group: one band over the GPUs of a node (BASELINE configs[4]).  groups = 2, 4 or 8: this block (one flow graph and one
+    //         process per GPU, every one fed the same stream) decodes interleaved channel group `group` only -- cfg.wideband_groups of
+    //         include/amps_recc.h; channel numbers on the ports stay whole-band numbers.
+    static sptr make(int n_channels = 832, int first_bin = 96, int slicer = -1, int groups = 0, int group = 0);
+    // Let ONE rank own the stream: after this call (a collective over all `nranks` blocks; `id` = the 128 bytes one of them got from
+    // rccl_unique_id(), carried between the processes by the application) work() broadcasts rank `root`'s input over xGMI with RCCL
+    // inside amps_recc_push_wideband_bcast; the other ranks' input only paces their flow graphs (same item counts: e.g. a null
+    // source behind the same throttle) and is ignored.
+    virtual void set_rccl(const std::string &id, int nranks, int rank, int root = 0) = 0;
+    static std::string rccl_unique_id();
 };
 
 } // namespace amps

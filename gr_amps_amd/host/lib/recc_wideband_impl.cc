@@ -5,6 +5,7 @@
 #include <stdexcept>
 #include <vector>
 #include "amps_recc.h"
+#include <string>
 
 namespace gr {
 namespace amps {
@@ -15,9 +16,11 @@ class recc_wideband_impl : public recc_wideband {
     std::vector<unsigned char> d_bursts;
     static const int kMaxPush = 1 << 22;          // wideband samples per push (8192 frames)
     static const int kMaxRecs = 4096;
+    bool d_bcast = false;                          // set_rccl: the stream comes from rank d_root by RCCL
+    int d_root = 0, d_rank = 0;
 
 public:
-    recc_wideband_impl(int C, int first_bin, int slicer)
+    recc_wideband_impl(int C, int first_bin, int slicer, int groups, int group)
         : gr::sync_block("recc_wideband", gr::io_signature::make(1, 1, 2 * sizeof(float)), gr::io_signature::make(0, 0, 0)), d_handle(nullptr),
           d_recs(kMaxRecs), d_bursts((size_t)kMaxRecs * AMPS_RECC_CAPTURE_SYMS)
     {
@@ -28,7 +31,10 @@ public:
         cfg.max_samples_per_push = kMaxPush / 512 + 72;
         cfg.max_bursts = kMaxRecs;
         cfg.device = -1;
-        cfg.flags = AMPS_RECC_FLAG_KEEP_BURSTS | (slicer == 1 ? AMPS_RECC_FLAG_SLICER_PRODUCT : slicer == 2 ? AMPS_RECC_FLAG_SLICER_SINE : 0u);
+        cfg.flags = AMPS_RECC_FLAG_KEEP_BURSTS | (slicer == 0 ? AMPS_RECC_FLAG_SLICER_ATAN : slicer == 1 ? AMPS_RECC_FLAG_SLICER_PRODUCT
+                                                  : slicer == 2 ? AMPS_RECC_FLAG_SLICER_SINE : slicer == 3 ? AMPS_RECC_FLAG_SLICER_EXACT : 0u);
+        cfg.wideband_groups = (uint32_t)groups;
+        cfg.wideband_group = (uint32_t)group;
         cfg.wideband_channels = 1024;
         cfg.wideband_decim = 512;
         cfg.wideband_taps_per_branch = 8;
@@ -40,6 +46,14 @@ public:
     }
     ~recc_wideband_impl() { amps_recc_destroy(d_handle); }
 
+    void set_rccl(const std::string &id, int nranks, int rank, int root)
+    {
+        if (id.size() != AMPS_RECC_RCCL_ID_BYTES) throw std::runtime_error("amps::recc_wideband: the RCCL id is 128 bytes");
+        int rc = amps_recc_rccl_init(d_handle, (const uint8_t *)id.data(), nranks, rank);
+        if (rc != 0) throw std::runtime_error(std::string("amps::recc_wideband: rccl: ") + amps_recc_strerror(rc));
+        d_bcast = true; d_root = root; d_rank = rank;
+    }
+
     int work(int noutput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &)
     {
         const float *in = (const float *)input_items[0];
@@ -47,7 +61,10 @@ public:
         while (done < noutput_items) {
             int n = noutput_items - done;
             if (n > kMaxPush) n = kMaxPush;
-            int rc = amps_recc_push_wideband(d_handle, in + 2 * (size_t)done, (size_t)n, AMPS_MEM_HOST);
+            int rc;
+            if (d_bcast)                            // every rank in step; only the root's items are read (staged to the device by the library)
+                rc = amps_recc_push_wideband_bcast(d_handle, d_rank == d_root ? in + 2 * (size_t)done : nullptr, (size_t)n, AMPS_MEM_HOST, d_root);
+            else rc = amps_recc_push_wideband(d_handle, in + 2 * (size_t)done, (size_t)n, AMPS_MEM_HOST);
             if (rc != 0) { std::fprintf(stderr, "amps::recc_wideband: %s\n", amps_recc_strerror(rc)); return WORK_DONE; }
             size_t nrec = 0;
             rc = amps_recc_drain_bursts(d_handle, d_recs.data(), d_bursts.data(), kMaxRecs, &nrec);
@@ -67,9 +84,17 @@ public:
     }
 };
 
-recc_wideband::sptr recc_wideband::make(int n_channels, int first_bin, int slicer)
+recc_wideband::sptr recc_wideband::make(int n_channels, int first_bin, int slicer, int groups, int group)
 {
-    return gnuradio::get_initial_sptr(new recc_wideband_impl(n_channels, first_bin, slicer));
+    return gnuradio::get_initial_sptr(new recc_wideband_impl(n_channels, first_bin, slicer, groups, group));
+}
+
+std::string recc_wideband::rccl_unique_id()
+{
+    std::string id(AMPS_RECC_RCCL_ID_BYTES, '\0');
+    int rc = amps_recc_rccl_unique_id((uint8_t *)&id[0]);
+    if (rc != 0) throw std::runtime_error(std::string("amps::recc_wideband: rccl: ") + amps_recc_strerror(rc));
+    return id;
 }
 
 } // namespace amps

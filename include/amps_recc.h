@@ -18,7 +18,8 @@
  *   amps_recc_push_wideband     <-  N x (freq_xlating_fir_filter_ccc -> the chain above), one per 30 kHz
  *                                   channel (grc/recctest.grc:889-937, taps :115-155); polyphase channelizer
  *                                   front end: M = 1024 branches at fs = 30.72 Msps, D = 512 (60 ksps per
- *                                   channel, samples_per_symbol = 3), 8 or 16 taps per branch
+ *                                   channel, samples_per_symbol = 3), 8 taps per branch: the one geometry
+ *                                   amps_recc_create accepts (anything else: -EINVAL)
  *   amps_recc_reply_words       <-  handle_response / handle_registration / handle_origination
  *                                   lib/recc_decode_impl.cc:181-272 + word builders lib/amps_packet.cc:26-95
  *
@@ -37,7 +38,8 @@
 extern "C" {
 #endif
 
-#define AMPS_RECC_ABI_VERSION 2   /* 2: amps_recc_cfg_t gained wideband_groups / wideband_group */
+#define AMPS_RECC_ABI_VERSION 3   /* 2: amps_recc_cfg_t gained wideband_groups / wideband_group; 3: default slicer = spec D, captures track the bit
+                                     clock unless AMPS_RECC_FLAG_FIXED_TIMING, amps_recc_rccl_* / _push_wideband_bcast / _debug_exact_slice added */
 
 /* protocol constants of the reference */
 #define AMPS_RECC_TRIGGER_SYMS 74   /* lib/recc_impl.cc:76-77: 37 bits x 2 Manchester symbols   */
@@ -147,9 +149,9 @@ typedef struct amps_recc_cfg {
     uint32_t max_bursts;           /* capacity of the device-side result list per push/drain (>=1)        */
     int32_t  device;               /* HIP device ordinal, -1 = current device                             */
     uint32_t flags;                /* AMPS_RECC_FLAG_*                                                    */
-    uint32_t wideband_channels;    /* channelizer seam: M branches (power of two, 0 = unused)             */
-    uint32_t wideband_decim;       /* channelizer seam: D input samples per output frame (M % D == 0)     */
-    uint32_t wideband_taps_per_branch; /* prototype length = taps_per_branch * M                         */
+    uint32_t wideband_channels;    /* channelizer seam: M branches: 1024 (0 = seam unused); other values: -EINVAL */
+    uint32_t wideband_decim;       /* channelizer seam: D input samples per output frame: 512 (2x oversampled)    */
+    uint32_t wideband_taps_per_branch; /* prototype length = taps_per_branch * M: 8 (0 selects 8)              */
     uint32_t wideband_first_channel;   /* first FFT bin that is an active RECC channel                    */
     uint32_t sync_tolerance;       /* IQ / wideband seams: accept a trigger with up to this many of its 74
                                     * symbols wrong.  0 = exact match, the reference's memmem
@@ -160,7 +162,8 @@ typedef struct amps_recc_cfg {
                                     * channels whose FFT bin k has (k mod 64) in [r * 64/G, (r+1) * 64/G): blocks of 64/G adjacent channels,
                                     * every 64 -- the split that lets a rank skip the last FFT pass and the slicer for everybody else's
                                     * bins.  n_channels / wideband_first_channel still describe the WHOLE band selection; records carry
-                                    * whole-band channel numbers; fused form only                                                    */
+                                    * whole-band channel numbers; fused form only, and the handle serves the wideband seam only:
+                                    * amps_recc_push_iq / _push_raw / _push_symbols answer -ENOSYS on it                                */
     uint32_t wideband_group;       /* channelizer seam: which group, 0 .. wideband_groups - 1                                          */
     void    *stream;               /* hipStream_t to launch on, NULL = library-owned stream               */
 } amps_recc_cfg_t;
@@ -288,6 +291,21 @@ int amps_recc_drain_bursts(amps_recc_t *h, amps_recc_burst_t *out, uint8_t *burs
  * channel for the last push_iq() call.  demod/soft/hard are host arrays of length n (may be NULL). */
 int amps_recc_debug_demod(amps_recc_t *h, const float *iq, size_t nsamp, int mem,
                           float *demod, float *soft, uint8_t *hard);
+
+/* ---- one band over the GPUs of a node (BASELINE configs[4]: "RCCL broadcast of wideband IQ over xGMI") ----
+ * One process and one handle per GPU, every handle created with cfg.wideband_groups = N, wideband_group = its rank.  Rank 0 (or
+ * any one rank) calls amps_recc_rccl_unique_id and the application carries the 128 bytes to the other ranks (a file, MPI,
+ * torch.distributed's store: the control plane is the application's); every rank then calls amps_recc_rccl_init -- a collective,
+ * it returns when all nranks have joined -- and from then on amps_recc_push_wideband_bcast in step: the root passes its block
+ * (`mem` says where it lives: a device block is used in place and stays untouched until the push after next or a drain, a host
+ * block is staged by the library and free on return), the others pass NULL; the block is broadcast by RCCL
+ * (ncclBroadcast) on a stream of the library's own into one of two receive buffers and pushed through the wideband seam
+ * of every rank, the broadcast of push i beside the kernels of push i - 1.  Records are drained per rank as ever and carry
+ * whole-band channel numbers.  RCCL is loaded at run time (librccl.so); -ENOSYS where it is absent.  nranks = 1 is valid. */
+#define AMPS_RECC_RCCL_ID_BYTES 128
+int amps_recc_rccl_unique_id(uint8_t id[AMPS_RECC_RCCL_ID_BYTES]);
+int amps_recc_rccl_init(amps_recc_t *h, const uint8_t id[AMPS_RECC_RCCL_ID_BYTES], int nranks, int rank);
+int amps_recc_push_wideband_bcast(amps_recc_t *h, const float *iq, size_t nsamp, int mem, int root);
 
 /* test tap of slicer spec D's bit logic, evaluated ON THE HOST by the very functions the kernels inline (no device needed):
  *   form 0: the streaming kernel's 32-sample window, oldest sample at bit 0: in = {SX, ST, SC}; out[0] = the slicer bits, exact from bit

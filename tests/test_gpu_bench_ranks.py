@@ -57,3 +57,18 @@ def test_two_ranks_one_band_by_channel_groups(gpu):
     assert c["channels_per_gpu"] == 416 and "channel groups" in c["parallelism"]
     assert c["checked"]["planted"] > 50 and c["checked"]["decoded_with_transmitted_MIN"] >= 0.97 * c["checked"]["planted"]
     assert abs(d["value"] - 832 * ((1 << 24) / 1536.0) * 3 / (d["ms_per_step"] * 3e-3) * 1e-6) < 1e-3 * d["value"]
+
+
+def test_one_rank_broadcast_inside_the_c_abi(gpu):
+    """--dist broadcast_abi with a world of one rank (AMPS_BENCH_FORCE_DIST=1: real RCCL, which refuses two ranks on one device): the
+    communicator id over torch.distributed's control plane, ncclCommInitRank + ncclBroadcast issued by the library, the records checked"""
+    env = dict(os.environ, AMPS_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_port()),
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--samples", str(1 << 24),
+           "--prewarm-ms", "20", "--no-cpu-baseline", "--no-other-specs", "--secondary", "none", "--dist", "broadcast_abi"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["dist"] == "broadcast_abi" and d["n_gpus"] == 1
+    c = d["config"]
+    assert c["channels_per_gpu"] == 832 and c["checked"]["decoded_with_transmitted_MIN"] >= 0.97 * c["checked"]["planted"] > 0
