@@ -290,51 +290,104 @@ __device__ __forceinline__ uint64_t capture_first_word(uint64_t nc, uint32_t sps
     const uint64_t lead = capture_lead(sps);
     return (nc > lead ? nc - lead : 0ull) >> 6;
 }
+// sum of v over the 64 lanes of the wave (DPP adds inside the rows, two row broadcasts, lane 63 read back): seven instructions, no LDS
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, true);    // row_ror:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, true);    // row_ror:8   -> every lane holds its row's sum
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2, 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 template <class Sync>
-__device__ __forceinline__ void manchester_from_ring(DecodeCore &s, const uint64_t *ring, uint64_t nc, uint64_t w0, uint32_t sps, int lane, bool track)
+__device__ __forceinline__ void manchester_from_ring(DecodeCore &s, const uint64_t *ring, uint64_t nc, uint64_t w0, uint32_t sps, int lane, bool track,
+                                                     bool keep_delays = true)
 {
     decode_core_begin(s, lane);
     Sync::sync();
     const uint32_t *r32 = (const uint32_t *)ring;
     const int32_t base = (int32_t)(nc - (w0 << 6));              // bit offset of n_c inside the window (< 2^20)
     const uint32_t midmask = (1u << (sps - 1)) - 1u;
-    int dly = 0, k0 = -TRACK_PRE_BITS;
-#pragma unroll 1
-    for (int b = 0; b < AMPS_TRACK_BLOCKS; b++) {
-        const int nb = b == 0 ? TRACK_PRE_BITS : b == 1 ? 7 + AMPS_RECC_WORD_BITS : AMPS_RECC_WORD_BITS;
-        const int k = k0 + lane;
-        const bool on = lane < nb;
-        const uint32_t na = (uint32_t)(base + (int32_t)sps * (2 * k + 1) + dly);     // first sampling instant of bit k
+    // The loop is a chain: block b's delay depends on block b - 1's measurement, and one wave issues an instruction every ~5 cycles,
+    // so what a round costs is its instruction count (first version: 190 instructions and an LDS round trip per round, 12 us per
+    // burst).  So: (1) a lane's window of block b + 1 is fetched while block b is being measured, one sample EARLY at block b's
+    // delay -- whatever block b decides (-1, 0, +1), the sps + 1 bits block b + 1 needs start 0, 1 or 2 bits into it -- and only the
+    // two raw dwords are fetched, the funnel shift that aligns them waits for the round that uses them; (2) the four statistics of a
+    // block travel in ONE wave sum (DPP adds); (3) the two irregular blocks (the trigger, the DCC + first repeat) are peeled off, so
+    // that the 34 regular rounds carry no per-block selects.
+    uint32_t f_lo = 0u, f_hi = 0u, f_sh = 0u;
+    int dly = 0, dly_fetched = 0;
+    uint32_t badacc = 0u;
+    // slicer bits from one before the first sampling instant of bit k at delay d (k, d from the caller; lanes beyond the block idle)
+    auto fetch = [&](int k, int d, bool on) {
+        const uint32_t na = (uint32_t)(base + (int32_t)sps * (2 * k + 1) + d - 1);
         const uint32_t q = on ? na >> 5 : 0u;
-        const uint32_t w = __builtin_amdgcn_alignbit(r32[q + 1], r32[q], na & 31u);  // bits na .. na + 31
+        f_lo = r32[q]; f_hi = r32[q + 1]; f_sh = na & 31u;
+    };
+    auto measure = [&](uint32_t w, bool on) {                      // the round's timing decision from the lanes' windows
         const uint32_t sa = w & 1u, sb = (w >> sps) & 1u;
-        const bool same = sa == sb;
-        if (on && k >= 0) s.bits[BOFF + k] = (uint8_t)(same ? (sa ^ 1u) : sb);
-        // bad pairs per record field: block 1 holds the DCC (bits 0..6) and repeat 0 of word 0, every later block lies inside one word
-        {
-            const uint64_t bad = __ballot(on && k >= 0 && same);
-            if (lane == 0 && b >= 1) {
-                if (b == 1) { s.bad[0] += (uint32_t)__popcll(bad & 0x7full); s.bad[1] += (uint32_t)__popcll(bad >> 7); }
-                else s.bad[1 + (k0 - 7) / 240] += (uint32_t)__popcll(bad);
-            }
+        const uint32_t mid = (w >> 1) & midmask;
+        const uint32_t cnt = (uint32_t)__popc(sa ? mid : (~mid & midmask));           // bits between the two instants that still equal a
+        // one wave sum for all four statistics: {sum of cnt, number of bits} of the falling pairs (a = 1) in the low half-word, of
+        // the rising ones in the high half-word (cnt <= 11 and at most 55 bits: 10 + 6 bits each)
+        const uint32_t contrib = (on && sa != sb) ? ((cnt | (1u << 10)) << (sa ? 0 : 16)) : 0u;
+        const uint32_t tot = wave_sum_u32(contrib);
+        const int sum1 = (int)(tot & 0x3ffu), n1 = (int)((tot >> 10) & 0x3fu), sum0 = (int)((tot >> 16) & 0x3ffu), n0 = (int)(tot >> 26);
+        const int E1 = 2 * sum1 - (int)(sps - 1) * n1, E0 = 2 * sum0 - (int)(sps - 1) * n0;
+        const int lhs = E1 * n0 + E0 * n1, rhs = 2 * n0 * n1;
+        if (rhs > 0) dly += lhs > rhs ? 1 : lhs < -rhs ? -1 : 0;
+    };
+    // ---- block 0: the 37 bits of the trigger, in front of the capture: measured only.  A trigger at the very start of a stream
+    // would put lane 0's early bit in front of the ring window: that lane fetches from bit 0 and skips its (unused) early bit
+    {
+        const int k = -TRACK_PRE_BITS + lane;
+        const bool on = lane < TRACK_PRE_BITS;
+        const int32_t nas = base + (int32_t)sps * (2 * k + 1) - 1;
+        const uint32_t na = nas < 0 ? 0u : (uint32_t)nas, q = on ? na >> 5 : 0u;
+        const uint32_t w = (nas < 0 ? r32[q] << 1 : __builtin_amdgcn_alignbit(r32[q + 1], r32[q], na & 31u)) >> 1;
+        fetch(lane, 0, lane < 7 + AMPS_RECC_WORD_BITS);           // block 1 = bits 0 .. 54
+        if (lane == 0 && keep_delays) s.dly[0] = 0;
+        if (track) measure(w, on);
+    }
+    // ---- block 1: the coded DCC (bits 0..6) and repeat 0 of word 0
+    {
+        const int k = lane;
+        const bool on = lane < 7 + AMPS_RECC_WORD_BITS;
+        const uint32_t w = __builtin_amdgcn_alignbit(f_hi, f_lo, f_sh) >> (uint32_t)(dly + 1);
+        if (lane == 0 && keep_delays) s.dly[1] = (int8_t)dly;
+        const int d1 = dly;
+        fetch(7 + AMPS_RECC_WORD_BITS + lane, d1, lane < AMPS_RECC_WORD_BITS);
+        const uint32_t sa = w & 1u, sb = (w >> sps) & 1u;
+        if (on) s.bits[BOFF + k] = (uint8_t)(sa == sb ? (sa ^ 1u) : sb);
+        const uint64_t bad = __ballot(on && sa == sb);
+        if (lane == 0) s.bad[0] = (uint32_t)__popcll(bad & 0x7full);
+        badacc = (uint32_t)__popcll(bad >> 7);
+        if (track) measure(w, on);
+        dly_fetched = d1;
+    }
+    // ---- blocks 2 .. 35: repeat r of word w (block = 1 + 5 w + r), 48 bits each
+    const bool on48 = lane < AMPS_RECC_WORD_BITS;
+    uint8_t *bitp = &s.bits[BOFF + 7 + AMPS_RECC_WORD_BITS + lane];
+    int kn = 7 + 2 * AMPS_RECC_WORD_BITS + lane;                  // this lane's bit in the block that is fetched next
+    int rep = 1, word = 0;
+#pragma unroll 1
+    for (int b = 2; b < AMPS_TRACK_BLOCKS; b++) {
+        const uint32_t w = __builtin_amdgcn_alignbit(f_hi, f_lo, f_sh) >> (uint32_t)(dly - dly_fetched + 1);
+        if (lane == 0 && keep_delays) s.dly[b] = (int8_t)dly;
+        dly_fetched = dly;
+        fetch(kn, dly, on48 && b + 1 < AMPS_TRACK_BLOCKS);        // (the last round fetches nothing it uses: q = 0)
+        kn += AMPS_RECC_WORD_BITS;
+        const uint32_t sa = w & 1u, sb = (w >> sps) & 1u;
+        if (on48) *bitp = (uint8_t)(sa == sb ? (sa ^ 1u) : sb);
+        bitp += AMPS_RECC_WORD_BITS;
+        badacc += (uint32_t)__popcll(__ballot(on48 && sa == sb));
+        if (++rep == AMPS_RECC_REPEATS) {                          // the word's five repeats are through
+            if (lane == 0) s.bad[1 + word] = badacc;
+            badacc = 0u; rep = 0; word++;
         }
-        if (lane == 0) s.dly[b] = (int8_t)dly;
-        if (track) {
-            const uint32_t mid = (w >> 1) & midmask;
-            const uint32_t cnt = (uint32_t)__popc(sa ? mid : (~mid & midmask));       // bits between the two instants that still equal a
-            const bool v1 = on && !same && sa, v0 = on && !same && !sa;
-            int sum1 = 0, sum0 = 0;
-#pragma unroll
-            for (int pl = 0; pl < 4; pl++) {                                          // cnt <= sps - 1 <= 11
-                sum1 += __popcll(__ballot(v1 && ((cnt >> pl) & 1u))) << pl;
-                sum0 += __popcll(__ballot(v0 && ((cnt >> pl) & 1u))) << pl;
-            }
-            const int n1 = __popcll(__ballot(v1)), n0 = __popcll(__ballot(v0));
-            const int E1 = 2 * sum1 - (int)(sps - 1) * n1, E0 = 2 * sum0 - (int)(sps - 1) * n0;
-            const int lhs = E1 * n0 + E0 * n1, rhs = 2 * n0 * n1;
-            if (rhs > 0) dly += lhs > rhs ? 1 : lhs < -rhs ? -1 : 0;
-        }
-        k0 += nb;
+        if (track) measure(w, on48);
     }
     Sync::sync();
 }

@@ -97,7 +97,7 @@ __device__ __forceinline__ void capture_decode_wave(const ResolveArgs &a, uint32
     DecodeCore &k = *(DecodeCore *)scratch;
     const uint64_t *s_ring = scratch + (sizeof(DecodeCore) + 7) / 8;
     const uint64_t w0 = capture_first_word(nc, a.sps);
-    manchester_from_ring<WaveSync>(k, s_ring, nc, w0, a.sps, lane, a.track != 0);
+    manchester_from_ring<WaveSync>(k, s_ring, nc, w0, a.sps, lane, a.track != 0, a.burst_syms != nullptr);
     tl.mark(0);
     decode_core_wave<WaveSync>(k, c, nc, nullptr, a.majority != 0, lane, tl);
 }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 evidence for one round: kernel-trace stats of the default bench command and separate PMC passes.
 # usage (GPU box, repo root): scripts/profile_round.sh <tag> [slicer]      -> gpurun_out/prof_<tag>/
-TAG=${1:-r03}; SL=${2:-atan}     # atan = spec A = the library default = what `python bench.py` runs
+TAG=${1:-r04}; SL=${2:-default}     # default = the library default (spec D since round 4) = what `python bench.py` runs
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 R=$PWD
@@ -14,8 +14,9 @@ rocprofv3 --output-format csv --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LD
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $SHORT > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $SHORT > $OUT/pmc_write.log 2>&1
 find $OUT -type f ! -name "*.csv" ! -name "*.log" -delete
-for k in "chz12_kernel" "recc_front_kernel<10" "recc_bits_kernel" "recc_resolve_kernel"; do echo "== $k"; python $R/scripts/pmc_summary.py $OUT "$k"; done | tee $OUT/pmc_kernels.txt
-python $R/scripts/make_traffic_json.py $OUT $SL > $OUT/traffic.json
+for k in "chz12_kernel" "recc_front_kernel<10" "recc_bits_kernel" "recc_resolve_kernel" "recc_symbols_kernel"; do echo "== $k"; python $R/scripts/pmc_summary.py $OUT "$k"; done | tee $OUT/pmc_kernels.txt
+SLNAME=$SL; if [ "$SL" = "default" ]; then SLNAME=$(cd $R && python -c "from gr_amps_amd import capi; print(capi.SLICER_NAMES[capi.load().amps_recc_default_slicer()])"); fi
+python $R/scripts/make_traffic_json.py $OUT $SLNAME > $OUT/traffic.json
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
 # keep the summaries, drop the raw per-dispatch tables (tens of MB: gpurun merges at most 64 MiB back)
 find $OUT -name "*counter_collection.csv" -delete

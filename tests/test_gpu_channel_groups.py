@@ -49,3 +49,20 @@ def test_group_argument_errors(gpu):
             capi.Recc(n_channels=CW, sps=3, max_samples=4096, max_bursts=16, wideband=dict(wb, **bad))
     with pytest.raises(capi.AmpsError):                            # channel groups exist in the fused form only
         capi.Recc(n_channels=CW, sps=3, max_samples=4096, max_bursts=16, unfused_wideband=True, wideband=dict(wb, groups=2, group=1))
+
+
+def test_a_group_handle_serves_the_wideband_seam_only(gpu):
+    """a channel-group handle owns its group's rows; the channel-major seams would take group rows for band channels and number their
+    records through the group's row map, so they refuse: -ENOSYS, and the handle keeps working"""
+    import errno
+    n = int(0.1 * sw.FS_WIDE) // D * D
+    with capi.Recc(n_channels=CW, sps=3, max_samples=n // D + 72, max_bursts=64,
+                   wideband={"channels": 1024, "decim": 512, "taps_per_branch": 8, "first_channel": FIRST, "groups": 2, "group": 1}) as r:
+        with pytest.raises(capi.AmpsError) as e:
+            r.push_iq(np.zeros((CW, 640), np.complex64))
+        assert e.value.code == -errno.ENOSYS
+        with pytest.raises(capi.AmpsError) as e:
+            r.push_symbols(np.zeros((CW, 100), np.uint8))
+        assert e.value.code == -errno.ENOSYS
+        r.push_wideband(np.zeros(n, np.complex64))
+        assert len(r.drain()) == 0
