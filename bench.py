@@ -72,6 +72,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-power-sample", action="store_true", help="do not sample package power / shader clock with rocm-smi during the timed region")
     ap.add_argument("--no-other-specs", action="store_true", help="skip the short runs of the other slicer specs")
+    ap.add_argument("--no-latency", action="store_true", help="skip the 20 ms-block real-time latency run (scripts/profile_round.sh: its small launches would dilute the per-kernel profile means)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args(argv)
 
@@ -626,7 +627,7 @@ def main(argv=None):
                             "roofline": sec["roofline"], "roofline_compute": sec["roofline_compute"]}
         if iq_base is None:
             iq_base = sec_base
-    if world == 1 and a.secondary != "none" and "secondary" in out:
+    if world == 1 and a.secondary != "none" and "secondary" in out and not a.no_latency:
         out["secondary"]["latency"] = realtime_latency(torch, a.slicer, local)
     if world > 1 and a.dist == "bands" and a.workload == "wideband832" and a.secondary != "none":
         # What BASELINE configs[4] names beside the band-per-GPU headline: ONE band, its block broadcast from rank 0 over xGMI inside

@@ -275,7 +275,10 @@ int front_depth(int slicer)
     static int env = -1;
     if (env < 0) { const char *e = std::getenv("AMPS_RECC_DEPTH"); env = e ? std::atoi(e) : 0; if (env < 0 || env > 3) env = 0; }
     if (env) return env;
-    return (slicer == AMPS_SLICER_ATAN_BOXCAR || slicer == AMPS_SLICER_EXACT) ? 1 : 2;   // spec D (round 4): 0.3285 at depth 1 against 0.3370 at depth 2 -- its sign logic is VALU work the fourth wave hides
+    // round 4: depth 2 is compiled for four waves per SIMD too (AMPS_FRONT_D2_BLOCKS = 4: a handful of prologue spills, none in the tile
+    // loop).  Same box, ms: spec A 0.3336 at depth 1 / 0.3343 at depth 2; D 0.3208 / 0.3174; B 0.3118 (three waves) -> 0.3038; C 0.3122 ->
+    // 0.3055.  The default spec keeps depth 1 -- 1 % slower and no scratch at all; the opt-in specs B and C take depth 2
+    return (slicer == AMPS_SLICER_ATAN_BOXCAR || slicer == AMPS_SLICER_EXACT) ? 1 : 2;
 }
 typedef void (*front_kernel_t)(FrontArgs);
 // the instantiation of the streaming kernel for (samples per symbol, slicer spec, tolerant sync, tiles in flight)

@@ -44,6 +44,14 @@ namespace amps {
 #ifndef AMPS_FRONT_NT
 #define AMPS_FRONT_NT 1                        // the tiles are read exactly once: non-temporal loads (measured 832 x 2^18: spec C 0.364 -> 0.327 ms, spec A 0.373 -> 0.349)
 #endif
+#ifndef AMPS_FRONT_D2_BLOCKS
+#define AMPS_FRONT_D2_BLOCKS 4                 // workgroups per CU the depth-2 / depth-3 instantiations are compiled for (register budget 512 / blocks).
+                                               // Round 4: with the rare paths' lane addresses no longer hoisted, depth 2 fits 128 registers: four waves per SIMD AND two
+                                               // tiles in flight (832 x 2^18, same box: B 0.3118 -> 0.3038 ms, C 0.3122 -> 0.3055, D 0.3208 -> 0.3174)
+#endif
+#ifndef AMPS_FRONT_D3_BLOCKS
+#define AMPS_FRONT_D3_BLOCKS 3
+#endif
 constexpr int TILE = AMPS_TILE_SAMPLES;      // 512 samples per wave tile
 constexpr int HALO = AMPS_HALO_SAMPLES;      // 1024 = 2 tiles of history per chunk / push
 constexpr int CARRY_CAP = HALO + 64;         // samples kept per channel between pushes
@@ -371,7 +379,7 @@ __host__ __device__ __forceinline__ uint32_t exact_slice_word3(uint32_t SX, uint
 // raw samples are staged in the wave's LDS buffer and each lane slices 8 consecutive samples with one v_pk_mul, one
 // v_sub and one v_alignbit each -- the kernel is then bound by its HBM reads alone.
 template <int SPS, int DEPTH, bool BITS = false, bool TOL = false, int SL = AMPS_SLICER_ATAN_BOXCAR>
-__global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc_front_kernel(FrontArgs a)
+__global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? AMPS_FRONT_D2_BLOCKS : AMPS_FRONT_D3_BLOCKS) void recc_front_kernel(FrontArgs a)
 {
     constexpr bool EXACT = SL == AMPS_SLICER_EXACT;
     constexpr bool PROD = SL == AMPS_SLICER_PRODUCT || EXACT;          // specs B and D stage the tile's raw samples in LDS
@@ -421,7 +429,7 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc
     }
 
   while (g0 < g1) {                                    // one segment = a run of tiles inside one channel
-    const int c = (int)(g0 / Tc);
+    const int c = __builtin_amdgcn_readfirstlane((int)(g0 / Tc));   // wave-uniform, but a 64-bit division runs on the VALU: back to an SGPR, and the segment's base pointers with it (they were the kernel's three spilled register pairs)
     const uint32_t t_lo = (uint32_t)(g0 - (uint64_t)c * Tc);
     uint32_t t_hi = t_lo + (uint32_t)(g1 - g0); if (t_hi > Tc) t_hi = (uint32_t)Tc;
     const uint32_t chunk = w_id - (uint32_t)(((uint64_t)c * Tc) / a.span);   // k-th segment of this channel
@@ -430,6 +438,9 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc
     g0 += (uint64_t)K;
     const float2 *blk = a.block + (uint64_t)c * a.ld;
     const float2 *car = a.carry + (uint64_t)c * CARRY_CAP;
+    int lane2 = 2 * lane;
+    asm volatile("" : "+v"(lane2));                      // opaque per segment: "block base + lane" must not be hoisted out of the segment loop
+    const float2 *blk_lane = blk + lane2;                // (as a 64-bit invariant of the whole kernel it was spilled at 128 registers)
 
     auto fetch = [&](int64_t i) -> float2 {   // generic path: carry then block; zero outside the data
         if (i >= avail || i < -(int64_t)HALO) return make_float2(0.f, 0.f);
@@ -439,7 +450,7 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc
     // one 512-sample tile: r[q] = samples (s0 + 128q + 2*lane, +1)
     auto load_tile = [&](float4 (&r)[4], int64_t s0) {
         if (s0 >= r_prev && s0 + TILE <= avail) {          // wave-uniform: entirely inside the new block
-            const f4a8 *p = (const f4a8 *)(blk + (s0 - r_prev)) + lane;
+            const f4a8 *p = (const f4a8 *)(blk_lane + (s0 - r_prev));
 #pragma unroll
 #if AMPS_FRONT_NT
             for (int q = 0; q < 4; q++) { f4a8 v = __builtin_nontemporal_load(p + 64 * q); r[q] = make_float4(v.x, v.y, v.z, v.w); }
@@ -447,9 +458,13 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc
             for (int q = 0; q < 4; q++) { f4a8 v = p[64 * q]; r[q] = make_float4(v.x, v.y, v.z, v.w); }
 #endif
         } else {
+            // (the lane's offset is made opaque here: otherwise its 64-bit sign extensions are hoisted out of the segment loop as
+            // invariants of this rare path and, at 128 registers, spilled -- the kernel's only scratch traffic in rounds 2 and 3)
+            int l2 = 2 * lane;
+            asm volatile("" : "+v"(l2));
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                float2 u = fetch(s0 + 128 * q + 2 * lane), w = fetch(s0 + 128 * q + 2 * lane + 1);
+                float2 u = fetch(s0 + 128 * q + l2), w = fetch(s0 + 128 * q + l2 + 1);
                 r[q] = make_float4(u.x, u.y, w.x, w.y);
             }
         }
@@ -531,7 +546,8 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc
                     at = __builtin_amdgcn_alignbit(at, __float_as_uint(it), 31);
                     ac = __builtin_amdgcn_alignbit(ac, __float_as_uint(ic), 31);
                     if (dbg) {
-                        int64_t rel = t0 + 8 * lane + q;
+                        int l8 = 8 * lane; asm volatile("" : "+v"(l8));   /* opaque: the debug tap's lane address is not a kernel-wide invariant worth a spilled register pair */
+                        int64_t rel = t0 + l8 + q;
                         if (rel < (int64_t)a.P) { a.dbg_d[rel] = it; a.dbg_S[rel] = ic; }
                     }
                 }
@@ -557,7 +573,8 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc
                 const float sd = m.y - m.x;
                 acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(sd), 31);
                 if (dbg) {
-                    int64_t rel = t0 + 8 * lane + q;
+                    int l8 = 8 * lane; asm volatile("" : "+v"(l8));   /* opaque: the debug tap's lane address is not a kernel-wide invariant worth a spilled register pair */
+                        int64_t rel = t0 + l8 + q;
                     if (rel < (int64_t)a.P) { a.dbg_d[rel] = 0.f; a.dbg_S[rel] = rel < (int64_t)a.force_ones ? 0.f : sd; }
                 }
             }
@@ -637,7 +654,8 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? 3 : 2) void recc
                 if constexpr (SL == AMPS_SLICER_SINE) byte |= (~__float_as_uint(s) >> 31) << q;   // g = !signbit(S')
                 else byte |= (s >= 0.0f ? 1u : 0u) << q;
                 if (dbg) {
-                    int64_t rel = t0 + 8 * lane + q;
+                    int l8 = 8 * lane; asm volatile("" : "+v"(l8));   /* opaque: the debug tap's lane address is not a kernel-wide invariant worth a spilled register pair */
+                        int64_t rel = t0 + l8 + q;
                     if (rel < (int64_t)a.P) { a.dbg_d[rel] = v[q + H]; a.dbg_S[rel] = s; }
                 }
             }

@@ -6,9 +6,9 @@ OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --no-cpu-baseline --no-other-specs --slicer $SL"          # the default command (12000 steps of wideband832 + 2000 of direct832) without its CPU legs
+BENCH="python $R/bench.py --no-cpu-baseline --no-other-specs --no-latency --slicer $SL"          # the default command (12000 steps of wideband832 + 2000 of direct832) without its CPU legs
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
-SHORT="python $R/bench.py --steps 4 --warmup 2 --prewarm-ms 50 --no-cpu-baseline --no-other-specs --slicer $SL"
+SHORT="python $R/bench.py --steps 4 --warmup 2 --prewarm-ms 50 --no-cpu-baseline --no-other-specs --no-latency --slicer $SL"
 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmc1 -o pmc -- $SHORT > $OUT/pmc1.log 2>&1
 rocprofv3 --output-format csv --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU GRBM_GUI_ACTIVE -d $OUT/pmc2 -o pmc -- $SHORT > $OUT/pmc2.log 2>&1
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $SHORT > $OUT/pmc_fetch.log 2>&1

@@ -36,9 +36,14 @@ def test_filter_bank_kernel_budget(res):
 def test_streaming_kernel_budget(res):
     for sps in (3, 4, 5, 6, 8, 10, 12):
         for name, r in _one(res, "void amps::recc_front_kernel<%d, 1, false, false, " % sps).items():
-            assert r["vgprs"] <= 128 and r["waves_per_simd"] == 4, (name, r)
+            assert r["vgprs"] <= 128 and r["waves_per_simd"] >= 4, (name, r)
             assert r["scratch_bytes_per_lane"] <= 64, (name, r)        # a few spilled loop invariants, none in the tile loop
             assert r["lds_bytes"] <= 40 * 1024, (name, r)              # four workgroups per CU
+    # the instantiations a handle takes by default at the bench's sample rate (depth 1; spec D = the default, spec A) spill nothing
+    # at all since round 4 (the rare paths' lane addresses are no longer hoisted into kernel-wide invariants)
+    for sl in (0, 3):
+        for name, r in _one(res, "void amps::recc_front_kernel<10, 1, false, false, %d>" % sl).items():
+            assert r["vgpr_spill"] == 0 and r["scratch_bytes_per_lane"] == 0, (name, r)
 
 
 def test_small_kernels_fit_many_per_cu(res):
