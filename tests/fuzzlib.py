@@ -1,7 +1,8 @@
 """Randomised differential cases for the fused IQ seam: GPU records vs the CPU model (oracle/fused_model.c), byte for byte.
 Random samples-per-symbol, channel count, SNR (8..30 dB), burst placement (incl. truncated bursts, damaged preambles and
 triggers inside a hold-off window), push schedule (sync drains, split drains, several pushes per drain), sync tolerance,
-slicer spec (A / B / C of include/amps_recc_numerics.h), host- or device-resident blocks.  Used by tests/test_gpu_fuzz.py and scripts/fuzz_parity.py.
+slicer spec (A / B / C / D of include/amps_recc_numerics.h), symbol-clock and carrier offsets of the mobile, tracked or fixed capture timing
+(round 4), host- or device-resident blocks.  Used by tests/test_gpu_fuzz.py and scripts/fuzz_parity.py.
 
 History: the first campaign (150 cases) failed 48 times -- host-resident blocks pushed back to back without a drain in
 between could be overwritten in the device staging buffer while the previous push's kernels were still reading it (a
@@ -23,7 +24,10 @@ def build_case(case, seed0):
     C = int(rng.integers(1, 5))
     tol = int(rng.choice([0, 0, 0, 1, 2, 4, 8]))
     majority = bool(rng.integers(0, 4) == 0)
-    slicer = int(rng.choice([0, 0, 1, 2, 2]))              # numeric spec of the slicer: A (default), B, C
+    slicer = int(rng.choice([0, 3, 3, 1, 2]))              # numeric spec of the slicer: A, D (default since round 4), B, C
+    fixed = bool(rng.integers(0, 4) == 0)                   # AMPS_RECC_FLAG_FIXED_TIMING: one case in four
+    ppm = float(rng.choice([0.0, 0.0, 100.0, -100.0, 400.0, -700.0, 1500.0]))
+    cfo = float(rng.choice([0.0, 0.0, 1000.0, -2000.0, 3000.0]))
     specs, N = [], 0
     for _ in range(C):
         off, bursts = int(rng.integers(200, 5000)), []
@@ -40,25 +44,25 @@ def build_case(case, seed0):
         N = max(N, off + 3000)
     N = int(N)
     snr = float(rng.uniform(8, 30))
-    iq = np.stack([synth.fsk_modulate(N, b, sps=sps, fs=20e3 * sps, snr_db=snr, rng=rng) for b in specs])
+    iq = np.stack([synth.fsk_modulate(N, b, sps=sps, fs=20e3 * sps, snr_db=snr, rng=rng, sym_ppm=ppm, cfo_hz=cfo) for b in specs])
     # one case in three runs on a handle padded with idle (all-zero) channels to 64 and more: there the resolve kernel's own
     # workgroup decodes its channel's captures; below 64 channels they go through the capture queue (recc_resolve.hip.h)
     pad = int(rng.integers(64, 80)) if rng.integers(0, 3) == 0 else 0
-    return rng, dict(sps=sps, C=C, tol=tol, majority=majority, slicer=slicer, snr=round(snr, 1), N=N, pad=pad), iq
+    return rng, dict(sps=sps, C=C, tol=tol, majority=majority, slicer=slicer, snr=round(snr, 1), N=N, pad=pad, fixed=fixed, ppm=ppm, cfo=cfo), iq
 
 
 def run_case(case, seed0, resident=False, keep_host=False):
     """returns (ok, info)"""
     rng, info, iq = build_case(case, seed0)
     sps, C, tol, N = info["sps"], info["C"], info["tol"], info["N"]
-    want = oracle.fused_push_all(iq, sps=sps, tolerance=tol, majority=info["majority"], slicer=info["slicer"])
+    want = oracle.fused_push_all(iq, sps=sps, tolerance=tol, majority=info["majority"], slicer=info["slicer"], tracking=not info["fixed"])
     if resident:
         import torch
     Cg = C + info["pad"]
     if info["pad"]:
         iq = np.concatenate([iq, np.zeros((info["pad"], N), iq.dtype)])
     with capi.Recc(n_channels=Cg, sps=sps, max_samples=N, max_bursts=256, sync_tolerance=tol, majority=info["majority"],
-                   slicer=("atan", "product", "sine")[info["slicer"]]) as r:
+                   slicer=("atan", "product", "sine", "exact")[info["slicer"]], fixed_timing=info["fixed"]) as r:
         off, recs, pipelined, open_, keep = 0, [], bool(rng.integers(0, 2)), False, []
         while off < N:
             b = int(min(N - off, rng.integers(1, max(2, N // 2))))
