@@ -439,6 +439,9 @@ __device__ __forceinline__ void chz_ring_wait(cf2 (&ring)[4][P + 4])
 // steps in a four-slot ring of 4 x 4 frame buffers = 136 KB of LDS; every role stays below 168 VGPRs: three waves per SIMD.
 // The unfused form is the same kernel with a different epilogue (MODE = CHZ12_IQ: the bins leave as 32-byte runs of the
 // channel-major block), so fused and unfused forms stay bit-identical by construction.
+#ifndef CHZ_EXACT_SPLIT_SLICER
+#define CHZ_EXACT_SPLIT_SLICER 0     // spec D: the second of the slicer role's two channel pairs sliced by the pass-2 role's waves (they idle half a step)
+#endif
 #ifndef CHZ_EXACT_P3_WITH_P2
 #define CHZ_EXACT_P3_WITH_P2 0       // spec D: pass 3 in the pass-2 role's waves (as under spec A) instead of the slicer role's
 #endif
@@ -621,7 +624,8 @@ template <int SL, bool IQ, int J0, int NP> struct ChzSlicer {
         if constexpr (!IQ) {
             if (a.stream_start && F < 0) {                // frames before the stream are exactly +0 (the FFT of zeros may hold -0):
                 asm volatile("" ::: "memory");            // the state they leave is that of a fresh stream (a real branch, twice per launch)
-                S[0].reset(); S[1].reset();
+#pragma unroll
+                for (int j = 0; j < NP; j++) S[j].reset();
             }
             if constexpr (SL == AMPS_SLICER_EXACT) {
                 // the word boundary inside the pre-roll (f0 - 1): latch the previous-word state the first real word needs
@@ -726,6 +730,7 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
     // Which role runs pass 3.  Behind the cheap slicers (specs B, C: 7 instructions per channel pair and frame) it shares the
     // slicer's waves; spec A's arctangent makes the slicer the longest chain of a time step (46 instructions per pair and
     // frame), so there pass 3 moves to the pass-2 waves (spec A 0.537 -> 0.517 ms, spec C 0.399 -> 0.414 if it moved too).
+    constexpr bool SPLIT_SLICER = !IQ && SL == AMPS_SLICER_EXACT && CHZ_EXACT_SPLIT_SLICER;
     constexpr bool P3_WITH_P2 = !IQ && (SL == AMPS_SLICER_ATAN_BOXCAR || (SL == AMPS_SLICER_EXACT && CHZ_EXACT_P3_WITH_P2));   // (handing one of the slicer's two channel pairs to the pass-2 role instead: 0.518 against 0.494)
     const int wf = wave & 3;                                            // frame of a half-batch this wave transforms (roles 1, 2)
     // Pass 3 produces the bins n = i (mod 64) from the points i + 64 r: a handle that decodes one channel group only needs the grp_w
@@ -734,7 +739,12 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
     const uint32_t p3_v = 64u * (uint32_t)wf + (uint32_t)lane;
     const bool p3_on = p3_v < 4u * a.grp_w;
     const int p3_f = (int)(p3_v / a.grp_w) & 3, p3_i = (int)(a.grp_r * a.grp_w + p3_v % a.grp_w);
-    if (role == 2) __builtin_amdgcn_s_setprio(2); else if (role == 1) __builtin_amdgcn_s_setprio(1);   // (six other priority triples measured: all within the run-to-run noise of this one)
+#ifndef CHZ_PRIO_SLICER
+#define CHZ_PRIO_SLICER 2
+#define CHZ_PRIO_PASS2 1
+#define CHZ_PRIO_FOLD 0
+#endif
+    if (role == 2) __builtin_amdgcn_s_setprio(CHZ_PRIO_SLICER); else if (role == 1) __builtin_amdgcn_s_setprio(CHZ_PRIO_PASS2); else __builtin_amdgcn_s_setprio(CHZ_PRIO_FOLD);   // (six other priority triples measured in round 3, four under spec D in round 4: all within the run-to-run noise of this one)
     // The next launch's carry (the last L - D + 4 D samples and the leftover) is a ~80 KB copy: every workgroup moves its slice
     // here, a sample per thread of wave 0, instead of a kernel of its own behind this one (4.4 us + a launch gap per push).  Not
     // in the fold waves: their vmcnt windows count their own loads only.
@@ -855,12 +865,15 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
 #pragma unroll
             for (int r = 1; r < 16; r++) tw3[r - 1] = chz_twiddle(r * p3_i, 1024);
         }
+        [[maybe_unused]] ChzSlicer<SL, IQ, 1, 1> slicer1;         // SPLIT_SLICER: channel pair 1 of every lane is sliced here
+        if constexpr (SPLIT_SLICER) slicer1.init(a, wf, lane);
         __syncthreads();                                          // all roles start together 
         {
             for (int i = 0; i < nh + 3; i++) {
                 const int h = i - 1, h3 = i - 2;
                 CHZ_STAMP(i, 0);
                 if (h >= 0 && h < nh) chz_p2(buf + ((h & (CHZ_SLOTS - 1)) * NB + wf) * CHZ_FB, lane);
+                if constexpr (SPLIT_SLICER) { if (i - 3 >= 0 && i - 3 < nh) slicer1.half(a, buf, fs, f0, f1, i - 3); }
                 CHZ_STAMP(i, 1);
                 if constexpr (P3_WITH_P2) { if (h3 >= 0 && h3 < nh && p3_on) chz_p3(buf + ((h3 & (CHZ_SLOTS - 1)) * NB + p3_f) * CHZ_FB, tw3, p3_i); }
                 CHZ_STAMP(i, 3);
@@ -876,7 +889,7 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
 #pragma unroll
             for (int r = 1; r < 16; r++) tw3[r - 1] = chz_twiddle(r * p3_i, 1024);
         }
-        ChzSlicer<SL, IQ, 0, 2> slicer;
+        ChzSlicer<SL, IQ, 0, SPLIT_SLICER ? 1 : 2> slicer;
         slicer.init(a, wf, lane);
         __syncthreads();                                          // all roles start together 
         {
