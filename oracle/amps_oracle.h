@@ -123,7 +123,7 @@ void         orc_fused_free(orc_fused_t *);
 void         orc_fused_set_tolerance(orc_fused_t *, int k);
 void         orc_fused_set_majority(orc_fused_t *, int on);   /* captures decoded in the product's majority mode */
 void         orc_fused_set_tracking(orc_fused_t *, int on);   /* timing tracking in the capture (default on; off = AMPS_RECC_FLAG_FIXED_TIMING) */
-void         orc_fused_set_slicer(orc_fused_t *, int spec);   /* AMPS_SLICER_* (include/amps_recc_numerics.h); default spec A */
+void         orc_fused_set_slicer(orc_fused_t *, int spec);   /* AMPS_SLICER_* (include/amps_recc_numerics.h); default = AMPS_SLICER_DEFAULT (spec D) */
 /* push n new samples of this channel; returns number of records appended to out */
 size_t       orc_fused_push(orc_fused_t *, const float *iq, size_t n, amps_recc_burst_t *out, size_t cap);
 /* taps for tolerance tests: d, S and g of the stream pushed so far (valid for the processed prefix) */

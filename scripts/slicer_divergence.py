@@ -1,4 +1,4 @@
-"""Word-level divergence of the atan-free slicer specs (B: product detector, C: sine discriminator) from the default spec A over
+"""Word-level divergence of the atan-free slicer specs (B: product detector, C: sine discriminator) from spec A (the default of rounds 1-3; spec D since) over
 SNR, on the IQ seam (10 samples per symbol, SNR in the 200 kHz sample bandwidth) and on the wideband seam (SNR in a channel's 60 kHz).
 For every SNR: bursts transmitted / found (trigger) / decoded with the transmitted MIN and all sent words valid, per spec, and the
 number of bursts whose decoded words differ from spec A's.  usage (GPU box): python scripts/slicer_divergence.py [bursts_per_point]"""

@@ -3,7 +3,7 @@
   spec C (AMPS_RECC_FLAG_SLICER_SINE):    spec A's boxcar over Im(x[n] conj(x[n-1])), no arctangent;
   spec D (AMPS_RECC_FLAG_SLICER_EXACT):   the sign of spec A's boxcar sum from sign bits and the winding number.
 Every check goes through the C ABI and compares with the CPU model (oracle/fused_model.c, orc_fused_set_slicer)
-bit for bit; the words must also equal those of the default spec A on the same bursts."""
+bit for bit; the words must also equal those of spec A (the arctangent discriminator, the default of rounds 1-3) on the same bursts."""
 import numpy as np
 import pytest
 
