@@ -421,6 +421,7 @@ int run_iq_device(amps_recc *h, const float2 *iq, uint64_t ld, uint32_t nsamp)
         fa.force_ones = ((h->slicer == AMPS_SLICER_PRODUCT || h->slicer == AMPS_SLICER_EXACT) && h->n_done == h->origin) ? h->sps : 0u;   // specs B, D: no partner yet
         fa.status = h->status; fa.dbg_d = h->dbg_d; fa.dbg_S = h->dbg_S; fa.dbg_channel = 0;
         front_housekeeping_args(h, fa);
+        fa.carry_out = h->carry[h->carry_cur ^ 1]; fa.carry_n = HALO + r_new;     // the next push's carry is written by the streaming kernel itself
         SpanGuard g(h, T_FRONT, P);
         if (debug_sync_enabled())
             std::fprintf(stderr, "amps_recc[debug]: front waves=%u span=%u Tc=%u C=%u P=%u avail=%u r_prev=%u ld=%llu n_done=%llu ring_words=%u max_chunks=%u det_cap=%u\n",
@@ -429,7 +430,7 @@ int run_iq_device(amps_recc *h, const float2 *iq, uint64_t ld, uint32_t nsamp)
         if (rc) return rc;
     }
     if (int rc = debug_sync(h, "front")) return rc;
-    {
+    if (!P) {                                              // a push too short for a 64-sample word only moves the carry
         CarryArgs ca{};
         ca.block = iq; ca.carry_in = h->carry[h->carry_cur]; ca.carry_out = h->carry[h->carry_cur ^ 1];
         ca.ld = ld; ca.r_prev = h->r_prev; ca.avail = avail; ca.P = P; ca.r_new = r_new;

@@ -102,6 +102,8 @@ struct FrontArgs {
     uint32_t force_ones;     // spec B: rel samples [0, force_ones) have no partner yet (stream start): g = 1
     uint32_t *zero1;         // housekeeping done by thread 0 of the launch instead of separate memsets on the stream: one dword to
     uint32_t *zero2;         // clear (the capture queue count) and an optional pair (the idle record list's {count, status})
+    float2   *carry_out;     // optional: the NEXT push's carry, [C][CARRY_CAP], written by this launch (a slice per wave) instead of by
+    uint32_t carry_n;        // recc_carry_kernel behind it: carry_out[c][k] = sample P - HALO + k, k < carry_n = HALO + leftover
 };
 __device__ __forceinline__ void front_housekeeping(const FrontArgs &a)
 {
@@ -405,6 +407,20 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? AMPS_FRONT_D2_BL
     const uint64_t g_end_all = (uint64_t)a.n_channels * Tc;
     uint64_t g0 = (uint64_t)w_id * a.span;
     uint64_t g1 = g0 + a.span; if (g1 > g_end_all) g1 = g_end_all;
+    if (!BITS && a.carry_out) {
+        // round 4: the ~9 KB per channel the next push starts from are copied here, 1-4 samples per lane, instead of by a kernel of
+        // their own behind this one (5 us + a launch gap per push); the two carry buffers alternate, so nothing read below is written
+        const uint32_t nw_all = gridDim.x * 4u;
+        const uint32_t total = a.n_channels * a.carry_n;
+        const uint32_t per = (total + nw_all - 1) / nw_all;
+        const uint32_t e1 = w_id * per + per < total ? w_id * per + per : total;
+        for (uint32_t e = w_id * per + (uint32_t)lane; e < e1; e += 64) {
+            const uint32_t cc = e / a.carry_n, k = e - cc * a.carry_n;
+            const int64_t i = (int64_t)a.P - HALO + k;
+            a.carry_out[(uint64_t)cc * CARRY_CAP + k] = i < (int64_t)a.r_prev ? a.carry[(uint64_t)cc * CARRY_CAP + HALO + i]
+                                                                              : a.block[(uint64_t)cc * a.ld + (i - a.r_prev)];
+        }
+    }
     const int64_t words_end = (int64_t)a.P / 64;          // rel word index limit of this launch
     const int r_prev = (int)a.r_prev, avail = (int)a.avail;
     float *s_d = s_d_all[wv];
