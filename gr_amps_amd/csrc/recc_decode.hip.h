@@ -462,9 +462,12 @@ __device__ __forceinline__ void decode_core_wave(DecodeCore &s, uint32_t channel
             o.valid[w] = (uint8_t)ok;
             int agree = 0;
             for (int r = 0; r < 5; r++) {
-                int same = 1;
-                for (int b = 0; b < 48; b++) if (s.bits[BOFF + 7 + 240 * w + 48 * r + b] != o.word_raw[w][b]) { same = 0; break; }
-                agree += same;
+                // branch-free: an early exit from the unrolled comparison nested 48 saved EXEC masks per repeat -- the ~400 spilled
+                // SGPRs of every kernel this function is inlined into (rounds 2-3)
+                unsigned diff = 0;
+#pragma unroll 8
+                for (int b = 0; b < 48; b++) diff |= (unsigned)(s.bits[BOFF + 7 + 240 * w + 48 * r + b] ^ o.word_raw[w][b]);
+                agree += diff == 0;
             }
             o.first_valid_rep[w] = (uint8_t)agree;
             o.manch_bad[w] = (uint16_t)s.bad[1 + w];

@@ -357,10 +357,16 @@ __global__ __launch_bounds__(64) void recc_decode_bursts_kernel(const uint8_t *b
 __global__ __launch_bounds__(256) void bch_encode_words_kernel(const uint8_t *msg, uint32_t n, int k, uint8_t *cw)
 {
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        uint8_t m[51], c[63];
-        for (int j = 0; j < k; j++) m[j] = msg[(uint64_t)i * k + j];
-        bch_short_encode(m, k, c);
-        for (int j = 0; j < k + 12; j++) cw[(uint64_t)i * (k + 12) + j] = c[j];
+        // systematic encode, parity = m(x) x^12 mod g(x) (bch_short_encode, in registers: no per-lane byte arrays)
+        unsigned rem = 0;
+        for (int j = 0; j < k; j++) {
+            const unsigned bit = msg[(uint64_t)i * k + j] & 1u;
+            const unsigned fb = ((rem >> 11) & 1u) ^ bit;
+            rem = (rem << 1) & 0xfffu;
+            if (fb) rem ^= 0x539u;
+            cw[(uint64_t)i * (k + 12) + j] = (uint8_t)bit;
+        }
+        for (int j = 0; j < 12; j++) cw[(uint64_t)i * (k + 12) + k + j] = (uint8_t)((rem >> (11 - j)) & 1u);
     }
 }
 __global__ __launch_bounds__(256) void bch_decode_words_kernel(const uint8_t *cw, uint32_t n, int k, uint8_t *msg, uint8_t *valid,
@@ -368,15 +374,22 @@ __global__ __launch_bounds__(256) void bch_decode_words_kernel(const uint8_t *cw
 {
     const int nb = k + 12;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        uint8_t c[63];
-        for (int j = 0; j < nb; j++) c[j] = cw[(uint64_t)i * nb + j] & 1u;
-        BchResult r = bch_short_decode(c, nb);
+        // the code word as a polynomial in one register (bit e = coefficient of x^e = byte nb - 1 - e): corrections are bit flips,
+        // not stores into a per-lane byte array at a computed index (which the compiler turned into 63 compare-and-select chains
+        // and 124 spilled SGPRs)
+        uint64_t w = 0;
+        for (int j = 0; j < nb; j++) w |= (uint64_t)(cw[(uint64_t)i * nb + j] & 1u) << (nb - 1 - j);
+        const uint64_t raw = w;
+        BchResult r = bch63_decode_packed(w);
         int ok = r.ok;
+#pragma unroll
         for (int f = 0; f < 3; f++) {
-            if (r.e[f] >= nb) ok = 0;                      // a "correction" inside the shortening zeros
-            else if (r.ok && r.e[f] >= 0) c[nb - 1 - r.e[f]] ^= 1u;
+            const int e = r.e[f];
+            if (e >= nb) ok = 0;                           // a "correction" inside the shortening zeros
+            else if (r.ok && e >= 0) w ^= 1ull << e;
         }
-        for (int j = 0; j < k; j++) msg[(uint64_t)i * k + j] = ok ? c[j] : (cw[(uint64_t)i * nb + j] & 1u);
+        const uint64_t out = ok ? w : raw;
+        for (int j = 0; j < k; j++) msg[(uint64_t)i * k + j] = (uint8_t)((out >> (nb - 1 - j)) & 1ull);
         valid[i] = (uint8_t)ok;
         nerr[i] = (uint8_t)(ok ? r.nflip : 0xff);
     }
