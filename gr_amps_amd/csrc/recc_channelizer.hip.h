@@ -584,7 +584,14 @@ template <int SL, bool IQ, int J0, int NP> struct ChzSlicer {
             pair_on[j] = __ballot(ch[j][0] < a.n_channels || ch[j][1] < a.n_channels) != 0;   // wave-uniform
         }
     }
-    // the four frames of half-batch hs: slice (or, unfused, store) this lane's bins
+    // the four frames of half-batch hs: slice (or, unfused, store) this lane's bins.
+    // KIND 0 = any half-batch (pre-roll, frames before the stream, the range's last one: every rare case behind a dynamic test);
+    // KIND 1 / 2 = a STEADY half-batch -- real frames (F >= f0), not the range's last, no stream-start reset -- that does not /
+    // does complete a 32-frame word.  Round 4: with the rare cases tested inside the hot loop every one of them was a control-flow
+    // merge through which the compiler carried the whole slicer state in a second register set: ~50 v_mov per time step and wave
+    // (8 % of the kernel's VALU instructions) for branches taken once in eight steps or twice per launch.  The role's loop now runs
+    // seven KIND-1 steps and one KIND-2 step per word, and KIND 0 only at the two ends of a workgroup's range.
+    template <int KIND = 0>
     __device__ __forceinline__ void half(const ChzArgs &a, const cf2 *buf, int64_t fs, int64_t f0, int64_t f1, int hs)
     {
         const int64_t F = fs + (int64_t)NB * hs;          // first frame of the half-batch (multiple of 4)
@@ -601,7 +608,7 @@ template <int SL, bool IQ, int J0, int NP> struct ChzSlicer {
             }
             if constexpr (IQ) {
                 // four frames of a bin leave as one 32-byte run of the channel-major block
-                const int ng = (int)(f1 - F < (int64_t)NB ? f1 - F : (int64_t)NB);
+                const int ng = KIND != 0 ? NB : (int)(f1 - F < (int64_t)NB ? f1 - F : (int64_t)NB);
 #pragma unroll
                 for (int e = 0; e < 2; e++) {
                     if (ch[j][e] < a.n_channels) {
@@ -621,26 +628,26 @@ template <int SL, bool IQ, int J0, int NP> struct ChzSlicer {
                 S[j].step4(yr, yi);
             }
         }
-        if constexpr (!IQ) {
-            if (a.stream_start && F < 0) {                // frames before the stream are exactly +0 (the FFT of zeros may hold -0):
+        if constexpr (!IQ && KIND != 1) {
+            if (KIND == 0 && a.stream_start && F < 0) {   // frames before the stream are exactly +0 (the FFT of zeros may hold -0):
                 asm volatile("" ::: "memory");            // the state they leave is that of a fresh stream (a real branch, twice per launch)
 #pragma unroll
                 for (int j = 0; j < NP; j++) S[j].reset();
             }
             if constexpr (SL == AMPS_SLICER_EXACT) {
                 // the word boundary inside the pre-roll (f0 - 1): latch the previous-word state the first real word needs
-                if (F < f0 && ((F + NB - 1) & 31) == 31) {
+                if (KIND == 0 && F < f0 && ((F + NB - 1) & 31) == 31) {
 #pragma unroll
                     for (int j = 0; j < NP; j++) { S[j].exact_word(0); S[j].exact_word(1); }
                 }
             }
-            if (F >= f0 && ((F + NB - 1) & 31) == 31) {   // 32 real frames collected (f0 is a multiple of 64)
+            if (KIND == 2 || (F >= f0 && ((F + NB - 1) & 31) == 31)) {   // 32 real frames collected (f0 is a multiple of 64)
                 // A channel's words leave as ONE 16-byte store per 128 frames (aligned group of four ring dwords): single
                 // dwords scattered over the channels' ring rows are counted -- and written -- as 32-byte sectors, 8x the 27 MB
                 // of slicer bits per GiB of input (round 1: 215 MB of 1.36 GB traffic).  Ranges start and end on 64-frame
                 // boundaries, so a run that is not a whole group is exactly two words.
                 const uint64_t w = (a.n_done + (uint64_t)(F + NB - 1)) >> 5;   // absolute ring dword of the finished word
-                const bool last = F + NB >= f1;
+                const bool last = KIND == 0 && F + NB >= f1;
 #pragma unroll
                 for (int j = 0; j < NP; j++)
 #pragma unroll
@@ -893,16 +900,31 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
         slicer.init(a, wf, lane);
         __syncthreads();                                          // all roles start together 
         {
-            for (int i = 0; i < nh + 3; i++) {
+            // time step i slices half-batch hs = i - 3 and transforms h3 = i - 2.  STEADY steps -- 2 <= hs <= nh - 2: real frames, not
+            // the range's last half-batch, h3 inside the range -- run without any of the rare-case tests (ChzSlicer::half<1 / 2>);
+            // a 32-frame word completes when hs = 1 (mod 8), i.e. in the last step of every group of eight that starts at i = 5
+            auto step = [&](auto kindc, int i) {
+                constexpr int KIND = decltype(kindc)::value;
                 const int hs = i - 3, h3 = i - 2;
                 CHZ_STAMP(i, 0);
-                if (hs >= 0 && hs < nh) slicer.half(a, buf, fs, f0, f1, hs);
+                if (KIND != 0 || (hs >= 0 && hs < nh)) slicer.template half<KIND>(a, buf, fs, f0, f1, hs);
                 CHZ_STAMP(i, 1);
-                if constexpr (!P3_WITH_P2) { if (h3 >= 0 && h3 < nh && p3_on) chz_p3(buf + ((h3 & (CHZ_SLOTS - 1)) * NB + p3_f) * CHZ_FB, tw3, p3_i); }
+                if constexpr (!P3_WITH_P2) { if ((KIND != 0 || (h3 >= 0 && h3 < nh)) && p3_on) chz_p3(buf + ((h3 & (CHZ_SLOTS - 1)) * NB + p3_f) * CHZ_FB, tw3, p3_i); }
                 CHZ_STAMP(i, 3);
                 __syncthreads();
                 CHZ_STAMP(i, 4);
+            };
+            constexpr int I_FIRST = IQ ? 3 + 2 : 5;               // first steady step (hs = 2)
+            const int i_last = nh + 1;                            // last steady step (hs = nh - 2, h3 = nh - 1)
+            int i = 0;
+            for (; i < nsteps && i < I_FIRST; i++) step(std::integral_constant<int, 0>{}, i);
+            while (i + 7 <= i_last) {
+#pragma unroll 1
+                for (int k = 0; k < 7; k++) step(std::integral_constant<int, 1>{}, i + k);
+                step(std::integral_constant<int, 2>{}, i + 7);
+                i += 8;
             }
+            for (; i < nsteps; i++) step(std::integral_constant<int, 0>{}, i);
         }
         CHZ_TL_FLUSH;
     }
