@@ -439,6 +439,9 @@ __device__ __forceinline__ void chz_ring_wait(cf2 (&ring)[4][P + 4])
 // steps in a four-slot ring of 4 x 4 frame buffers = 136 KB of LDS; every role stays below 168 VGPRs: three waves per SIMD.
 // The unfused form is the same kernel with a different epilogue (MODE = CHZ12_IQ: the bins leave as 32-byte runs of the
 // channel-major block), so fused and unfused forms stay bit-identical by construction.
+#ifndef CHZ_UNROLL_GROUP
+#define CHZ_UNROLL_GROUP 0          // the slicer role's group of eight steady steps as straight-line code (registers renamed across steps)
+#endif
 #ifndef CHZ_EXACT_SPLIT_SLICER
 #define CHZ_EXACT_SPLIT_SLICER 0     // spec D: the second of the slicer role's two channel pairs sliced by the pass-2 role's waves (they idle half a step)
 #endif
@@ -919,7 +922,11 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
             int i = 0;
             for (; i < nsteps && i < I_FIRST; i++) step(std::integral_constant<int, 0>{}, i);
             while (i + 7 <= i_last) {
+#if CHZ_UNROLL_GROUP
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
                 for (int k = 0; k < 7; k++) step(std::integral_constant<int, 1>{}, i + k);
                 step(std::integral_constant<int, 2>{}, i + 7);
                 i += 8;
