@@ -922,6 +922,14 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
             int i = 0;
             for (; i < nsteps && i < I_FIRST; i++) step(std::integral_constant<int, 0>{}, i);
             while (i + 7 <= i_last) {
+#if CHZ_UNROLL_GROUP == 2
+                // steps in pairs: the three-frame history of the slicer ping-pongs between two register sets instead of being moved
+                // back into place at the end of every step
+#pragma unroll 1
+                for (int k = 0; k < 6; k += 2) { step(std::integral_constant<int, 1>{}, i + k); step(std::integral_constant<int, 1>{}, i + k + 1); }
+                step(std::integral_constant<int, 1>{}, i + 6);
+                step(std::integral_constant<int, 2>{}, i + 7);
+#else
 #if CHZ_UNROLL_GROUP
 #pragma unroll
 #else
@@ -929,6 +937,7 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
 #endif
                 for (int k = 0; k < 7; k++) step(std::integral_constant<int, 1>{}, i + k);
                 step(std::integral_constant<int, 2>{}, i + 7);
+#endif
                 i += 8;
             }
             for (; i < nsteps; i++) step(std::integral_constant<int, 0>{}, i);
