@@ -41,7 +41,16 @@ def _touched(lines, rng, dst):
     return None
 
 
+LATCH = re.compile(r"\s*s_branch\s+(\.LBB\d+_\d+)")
+
+
 def scan(asm_text):
+    """Per chz12_kernel instantiation: (name, asm loads, waits of the loop that holds them, hazards).  A load is followed along the
+    loop's PATH: straight through the text, and at an unconditional `s_branch` to an EARLIER label (the loop's latch -- block
+    placement rotates the loop, so its last half-step ends in that branch and not in the text that happens to follow it) on at the
+    label.  Conditional branches are not taken: inside the loop they are its exits and the skips of its rare paths, wherever their
+    targets were placed.  The walk ends at the second `s_waitcnt vmcnt(8)` it meets, the wait that covers the load; nothing before
+    it may name one of the load's destination registers, and a walk that never gets there is reported too."""
     txt = asm_text.split("\n")
     out, i = [], 0
     while i < len(txt):
@@ -53,34 +62,51 @@ def scan(asm_text):
         while j < len(txt) and not txt[j].startswith(".Lfunc_end"):
             j += 1
         lines = txt[i:j]
+        labels = {}
+        for k, l in enumerate(lines):
+            lm = re.match(r"^(\.LBB\d+_\d+):", l)
+            if lm:
+                labels[lm.group(1)] = k
         waits = [k for k, l in enumerate(lines) if "s_waitcnt vmcnt(8)" in l]
         loads = [(k, _regs(LOAD.match(l).group(1))) for k, l in enumerate(lines) if LOAD.match(l)]
         # the unrolled loop that holds the asm loads: its waits are the ones with loads between them and their successor
         loop = [w for n, w in enumerate(waits) if any(w < k < (waits[n + 1] if n + 1 < len(waits) else w + 2000) for k, _ in loads)]
         issues = []
         for k, dst in loads:
-            nxt = [w for w in loop if w > k]
-            if len(nxt) >= 2:
-                segs = [range(k + 1, nxt[1])]
-            else:       # the last two half-steps of the unrolled period: on to the loop's end, then from its head to the covering wait
-                bar = next(q for q in range(loop[-1], len(lines)) if "s_barrier" in lines[q])    # the last half-step ends at its barrier
-                tail_end = min(len(lines), bar + 12)                                              # (+ the loop's back branch)
-                segs = [range(k + 1, tail_end), range(max(0, loop[0] - 30), loop[1 - len(nxt)])]
-            for seg in segs:
-                hit = _touched(lines, seg, dst)
-                if hit:
-                    issues.append((m.group(1), k + 1, hit[0] + 1, hit[1]))
-                    break
+            pos, seen, latched = k + 1, 0, set()
+            while pos < len(lines) and seen < 2:
+                t = lines[pos].strip()
+                if "s_waitcnt vmcnt(8)" in t:
+                    seen += 1
+                elif t and t[0] not in ";.":
+                    used = set()
+                    for tk in re.findall(r"v\[\d+:\d+\]|v\d+", t):
+                        used |= _regs(tk)
+                    if used & dst:
+                        issues.append((m.group(1), k + 1, pos + 1, t))
+                        break
+                    bm = LATCH.match(lines[pos])
+                    if bm and labels.get(bm.group(1), len(lines)) < pos and pos not in latched:
+                        latched.add(pos)
+                        pos = labels[bm.group(1)]
+                        continue
+                    if "s_endpgm" in t:
+                        break
+                pos += 1
+            else:
+                if seen < 2:
+                    issues.append((m.group(1), k + 1, pos, "path left the kernel before the covering wait"))
         out.append((m.group(1), len(loads), len(loop), issues))
         i = j
     return out
 
 
 def test_scanner_sees_a_planted_hazard():
-    asm = "\n".join(["_ZN4amps12chz12_kernelXX:", "s_waitcnt vmcnt(8)", "global_load_dwordx2 v[10:11], v1, s[2:3]", "v_mov_b64_e32 v[20:21], v[10:11]",
-                     "s_waitcnt vmcnt(8)", "global_load_dwordx2 v[12:13], v1, s[2:3]", "s_waitcnt vmcnt(8)", "v_add_f32 v0, v10, v12", "s_barrier", ".Lfunc_end0:"])
+    asm = "\n".join(["_ZN4amps12chz12_kernelXX:", ".LBB0_1:", "s_waitcnt vmcnt(8)", "global_load_dwordx2 v[10:11], v1, s[2:3]",
+                     "v_mov_b64_e32 v[20:21], v[10:11]", "s_cbranch_scc1 .LBB0_1", "s_barrier", "s_waitcnt vmcnt(8)",
+                     "global_load_dwordx2 v[12:13], v1, s[2:3]", "s_barrier", "s_branch .LBB0_1", "v_add_f32 v0, v10, v12", ".Lfunc_end0:"])
     res = scan(asm)
-    assert len(res) == 1 and len(res[0][3]) >= 1 and "v_mov_b64" in res[0][3][0][3]
+    assert len(res) == 1 and len(res[0][3]) == 1 and "v_mov_b64" in res[0][3][0][3]
 
 
 def test_no_register_with_a_load_in_flight_is_touched():
