@@ -598,6 +598,7 @@ def main(argv=None):
     is_default = a.slicer in ("default", lib_default)
     if a.slicer == "default":
         a.slicer = lib_default
+    broken_group = False
     res, iq_base = run_workload(a.workload, a, torch, dev, dist, rank, world, local, a.slicer, a.steps, a.warmup)
     res["config"]["slicer_is_library_default"] = is_default
     res["config"]["slicer_sensitivity"] = SLICER_SENSITIVITY
@@ -633,16 +634,22 @@ def main(argv=None):
         # What BASELINE configs[4] names beside the band-per-GPU headline: ONE band, its block broadcast from rank 0 over xGMI inside
         # the timed region (RCCL ncclBroadcast through torch.distributed), every rank decoding its interleaved channel group.  A short
         # pass, so that one driver invocation per N yields both curves; `scaling` of this entry is "strong" (one band whatever N).
+        # The headline above is already measured: whatever goes wrong in this pass is recorded in its place, not raised (a rank that
+        # raised has left the collectives, so the process group is then not torn down either -- see the end of main).
         bsteps = max(4, min(a.steps, 40))
-        b, _ = run_workload("wideband832", a, torch, dev, dist, rank, world, local, a.slicer, bsteps, min(a.warmup, 3), dist_mode="broadcast")
-        allk = torch.zeros(world, device=dev, dtype=torch.float64)         # per-rank kernel time, gathered with an all-reduce (gloo, the
-        allk[rank] = b["roofline"]["kernel_ms"]                            # test backend, has no all-gather for device tensors)
-        dist.all_reduce(allk, op=dist.ReduceOp.SUM)
-        out["secondary"] = {"workload": "wideband832, one band over all ranks (--dist broadcast)", "value": b["value"], "unit": "Msym/s", "steps": bsteps,
-                            "ms_per_step": b["ms_per_step"], "scaling": "strong", "config": b["config"],
-                            "collective": {"op": "broadcast of the step's 1 GiB fc32 block from rank 0, inside the timed region", "backend": dist.get_backend(),
-                                           "nranks": dist.get_world_size(), "bytes_per_step": 8 * b["config"]["samples_per_channel"] * 512},
-                            "kernel_ms_per_rank": [round(float(k), 4) for k in allk.tolist()], "roofline_rank0": b["roofline"]}
+        try:
+            b, _ = run_workload("wideband832", a, torch, dev, dist, rank, world, local, a.slicer, bsteps, min(a.warmup, 3), dist_mode="broadcast")
+            allk = torch.zeros(world, device=dev, dtype=torch.float64)     # per-rank kernel time, gathered with an all-reduce (gloo, the
+            allk[rank] = b["roofline"]["kernel_ms"]                        # test backend, has no all-gather for device tensors)
+            dist.all_reduce(allk, op=dist.ReduceOp.SUM)
+            out["secondary"] = {"workload": "wideband832, one band over all ranks (--dist broadcast)", "value": b["value"], "unit": "Msym/s", "steps": bsteps,
+                                "ms_per_step": b["ms_per_step"], "scaling": "strong", "config": b["config"],
+                                "collective": {"op": "broadcast of the step's 1 GiB fc32 block from rank 0, inside the timed region", "backend": dist.get_backend(),
+                                               "nranks": dist.get_world_size(), "bytes_per_step": 8 * b["config"]["samples_per_channel"] * 512},
+                                "kernel_ms_per_rank": [round(float(k), 4) for k in allk.tolist()], "roofline_rank0": b["roofline"]}
+        except Exception as e:                                             # noqa: BLE001 -- recorded, see above
+            out["secondary"] = {"workload": "wideband832, one band over all ranks (--dist broadcast)", "error": "%s: %s" % (type(e).__name__, e)}
+            broken_group = True
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         if iq_base is None:
             iq_base = make_batch(torch, torch.device("cpu"), 16, 1 << 18, 10, seed=1)[1]
@@ -650,7 +657,7 @@ def main(argv=None):
         if a.workload == "wideband832":
             out["cpu_baseline"]["sample"] += ("; per channel at 200 ksps, i.e. downstream of the per-channel 299-tap channel filter the reference "
                                                "would also run -- 'with_channel_filter' times the chain including it")
-    if dist is not None:
+    if dist is not None and not broken_group:
         dist.destroy_process_group()
     if rank == 0:          # the JSON line is the last thing written: RCCL's banner sits in the C library's stdout buffer until
         import ctypes      # exit when stdout is a pipe, so that buffer is flushed first
@@ -660,6 +667,9 @@ def main(argv=None):
             pass
         sys.stderr.flush()
         print(json.dumps(out), flush=True)
+    if broken_group:       # the ranks are no longer in step: leave without the collective teardown (the line above is out)
+        sys.stdout.flush()
+        os._exit(0 if rank == 0 else 1)
 
 
 if __name__ == "__main__":
