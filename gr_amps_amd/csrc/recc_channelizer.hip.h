@@ -439,15 +439,6 @@ __device__ __forceinline__ void chz_ring_wait(cf2 (&ring)[4][P + 4])
 // steps in a four-slot ring of 4 x 4 frame buffers = 136 KB of LDS; every role stays below 168 VGPRs: three waves per SIMD.
 // The unfused form is the same kernel with a different epilogue (MODE = CHZ12_IQ: the bins leave as 32-byte runs of the
 // channel-major block), so fused and unfused forms stay bit-identical by construction.
-#ifndef CHZ_UNROLL_GROUP
-#define CHZ_UNROLL_GROUP 0          // the slicer role's group of eight steady steps as straight-line code (registers renamed across steps)
-#endif
-#ifndef CHZ_EXACT_SPLIT_SLICER
-#define CHZ_EXACT_SPLIT_SLICER 0     // spec D: the second of the slicer role's two channel pairs sliced by the pass-2 role's waves (they idle half a step)
-#endif
-#ifndef CHZ_EXACT_P3_WITH_P2
-#define CHZ_EXACT_P3_WITH_P2 0       // spec D: pass 3 in the pass-2 role's waves (as under spec A) instead of the slicer role's
-#endif
 constexpr int CHZ_SLOTS = 4;                                     // half-batches in flight
 constexpr int CHZ_PREROLL = 8;                                   // frames re-run in front of a workgroup's range (two half-batches)
 constexpr int CHZ12_IQ = -1;                                     // MODE: write the channel-major block; >= 0: AMPS_SLICER_* fused behind the FFT
@@ -551,15 +542,15 @@ template <int SL> struct ChzSlicePair {
     }
 };
 
-// The slicer of a role: NP channel pairs per lane, pairs J0 .. J0 + NP - 1.
+// The slicer of the pass-3 role: NP = 2 channel pairs per lane (pairs J0 .. J0 + NP - 1 of the wave's eight).
 // Bin ownership.  The planar layout keeps a frame in eight blocks of 128 bins, [re of bins 0..63 | re of 64..127 | im | im]; a lane's
 // PAIR is two bins 64 apart in one block, so the four floats a frame brings for it sit at base + {0, 64, 128, 192} (two
 // ds_read2st64_b32) and arrive as the register pairs (re, re) and (im, im) of its two channels.  With W = grp_w residues per
 // block belonging to this handle (64 = all of them) a frame holds 8 W pairs, numbered vp = W * block + i'; pair j of (wave wf, lane)
 // is vp = 64 (4 (J0 + j) + wf) + lane.  W = 64: pair j holds bins 512 j + 128 wf + lane and + 64, consecutive lanes read consecutive
 // floats.  A pair-wave none of whose bins is decoded by this handle is skipped (wave-uniform).
-template <int SL, bool IQ, int J0, int NP> struct ChzSlicer {
-    static constexpr int NB = CHZ_BATCH, M = CHZ_M;
+template <int SL, bool IQ> struct ChzSlicer {
+    static constexpr int NB = CHZ_BATCH, M = CHZ_M, J0 = 0, NP = 2;   // channel pairs of a lane
     ChzSlicePair<SL> S[NP];
     uint32_t ch[NP][2];                                           // row of the bin (>= n_channels: not decoded by this handle)
     uint32_t pbase[NP];                                           // float offset of the pair's first real part in a planar frame
@@ -740,8 +731,10 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
     // Which role runs pass 3.  Behind the cheap slicers (specs B, C: 7 instructions per channel pair and frame) it shares the
     // slicer's waves; spec A's arctangent makes the slicer the longest chain of a time step (46 instructions per pair and
     // frame), so there pass 3 moves to the pass-2 waves (spec A 0.537 -> 0.517 ms, spec C 0.399 -> 0.414 if it moved too).
-    constexpr bool SPLIT_SLICER = !IQ && SL == AMPS_SLICER_EXACT && CHZ_EXACT_SPLIT_SLICER;
-    constexpr bool P3_WITH_P2 = !IQ && (SL == AMPS_SLICER_ATAN_BOXCAR || (SL == AMPS_SLICER_EXACT && CHZ_EXACT_P3_WITH_P2));   // (handing one of the slicer's two channel pairs to the pass-2 role instead: 0.518 against 0.494)
+    // Spec D keeps pass 3 beside its slicer like specs B / C: either placement 0.413-0.421 ms, and its second channel pair sliced by
+    // the pass-2 role's waves (which idle half a step) 0.425-0.428 against 0.420-0.428 -- the kernel is bound by VALU throughput, not
+    // by one role's chain (profiles/EXPERIMENTS.md, round 4).
+    constexpr bool P3_WITH_P2 = !IQ && SL == AMPS_SLICER_ATAN_BOXCAR;   // (handing one of the slicer's two channel pairs to the pass-2 role instead: 0.518 against 0.494)
     const int wf = wave & 3;                                            // frame of a half-batch this wave transforms (roles 1, 2)
     // Pass 3 produces the bins n = i (mod 64) from the points i + 64 r: a handle that decodes one channel group only needs the grp_w
     // residues of its group, so the four frames of a half-batch pack into 4 grp_w lanes: virtual lane v = 64 wf + lane transforms
@@ -875,15 +868,12 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
 #pragma unroll
             for (int r = 1; r < 16; r++) tw3[r - 1] = chz_twiddle(r * p3_i, 1024);
         }
-        [[maybe_unused]] ChzSlicer<SL, IQ, 1, 1> slicer1;         // SPLIT_SLICER: channel pair 1 of every lane is sliced here
-        if constexpr (SPLIT_SLICER) slicer1.init(a, wf, lane);
         __syncthreads();                                          // all roles start together 
         {
             for (int i = 0; i < nh + 3; i++) {
                 const int h = i - 1, h3 = i - 2;
                 CHZ_STAMP(i, 0);
                 if (h >= 0 && h < nh) chz_p2(buf + ((h & (CHZ_SLOTS - 1)) * NB + wf) * CHZ_FB, lane);
-                if constexpr (SPLIT_SLICER) { if (i - 3 >= 0 && i - 3 < nh) slicer1.half(a, buf, fs, f0, f1, i - 3); }
                 CHZ_STAMP(i, 1);
                 if constexpr (P3_WITH_P2) { if (h3 >= 0 && h3 < nh && p3_on) chz_p3(buf + ((h3 & (CHZ_SLOTS - 1)) * NB + p3_f) * CHZ_FB, tw3, p3_i); }
                 CHZ_STAMP(i, 3);
@@ -899,7 +889,7 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
 #pragma unroll
             for (int r = 1; r < 16; r++) tw3[r - 1] = chz_twiddle(r * p3_i, 1024);
         }
-        ChzSlicer<SL, IQ, 0, SPLIT_SLICER ? 1 : 2> slicer;
+        ChzSlicer<SL, IQ> slicer;
         slicer.init(a, wf, lane);
         __syncthreads();                                          // all roles start together 
         {
@@ -922,22 +912,9 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
             int i = 0;
             for (; i < nsteps && i < I_FIRST; i++) step(std::integral_constant<int, 0>{}, i);
             while (i + 7 <= i_last) {
-#if CHZ_UNROLL_GROUP == 2
-                // steps in pairs: the three-frame history of the slicer ping-pongs between two register sets instead of being moved
-                // back into place at the end of every step
 #pragma unroll 1
-                for (int k = 0; k < 6; k += 2) { step(std::integral_constant<int, 1>{}, i + k); step(std::integral_constant<int, 1>{}, i + k + 1); }
-                step(std::integral_constant<int, 1>{}, i + 6);
+                for (int k = 0; k < 7; k++) step(std::integral_constant<int, 1>{}, i + k);   // (all eight as straight-line code: 15 spilled VGPRs, no fewer moves)
                 step(std::integral_constant<int, 2>{}, i + 7);
-#else
-#if CHZ_UNROLL_GROUP
-#pragma unroll
-#else
-#pragma unroll 1
-#endif
-                for (int k = 0; k < 7; k++) step(std::integral_constant<int, 1>{}, i + k);
-                step(std::integral_constant<int, 2>{}, i + 7);
-#endif
                 i += 8;
             }
             for (; i < nsteps; i++) step(std::integral_constant<int, 0>{}, i);
