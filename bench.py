@@ -445,6 +445,12 @@ def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, w
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     tm = r.timing()
+    gathered = None
+    if wide and one_band and dist_mode == "broadcast_abi":
+        # outside the timed region: one more step whose records come back through the ABI's collective drain (amps_recc_drain_gather:
+        # every rank's list merged at rank 0) -- the whole band's bursts in one place, counted on the record
+        push()
+        gathered = int(len(r.drain_gather(root=0)))
     r.close()
     del batch
     torch.cuda.empty_cache()
@@ -498,6 +504,7 @@ def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, w
                    "channels_per_gpu": C, "samples_per_channel": N, "samples_per_symbol": sps, "slicer_spec": SLICERS[slicer],
                    "algorithmic_bytes_per_symbol": round(alg_bytes / syms_per_step_rank, 2),
                    "realtime_channels_per_gpu": round(value / world / 20e3, 1),
+                   **({"records_gathered_at_rank0_in_one_step": gathered} if gathered is not None else {}),
                    "bursts_decoded_per_step_per_gpu": nrec // max(1, steps), "checked": checked, "parallelism": par},
         "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,

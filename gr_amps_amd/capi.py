@@ -98,7 +98,7 @@ EXPORTS = (
     "amps_recc_drain_begin", "amps_recc_drain_end", "amps_recc_set_origin",
     "amps_recc_wait_event", "amps_recc_record_event", "amps_recc_refchain_symbols", "amps_recc_refchain_tables",
     "amps_recc_drain_bursts", "amps_recc_default_slicer", "amps_recc_debug_exact_slice",
-    "amps_recc_rccl_unique_id", "amps_recc_rccl_init", "amps_recc_push_wideband_bcast",
+    "amps_recc_rccl_unique_id", "amps_recc_rccl_init", "amps_recc_push_wideband_bcast", "amps_recc_drain_gather",
 )
 
 _lib = None
@@ -140,6 +140,8 @@ def load():
         L.amps_recc_rccl_unique_id.argtypes = [vp]
         L.amps_recc_rccl_init.argtypes = [vp, vp, C.c_int, C.c_int]
         L.amps_recc_push_wideband_bcast.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int]
+    if hasattr(L, "amps_recc_drain_gather"):
+        L.amps_recc_drain_gather.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.c_int]
     L.amps_recc_drain.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.amps_recc_refchain_symbols.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, vp, C.c_size_t, vp]
     L.amps_recc_refchain_tables.argtypes = [vp, vp, vp]
@@ -160,7 +162,7 @@ def load():
     L.amps_bch_decode_words.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, vp, vp, vp]
     for name in EXPORTS:
         if name in ("amps_recc_default_slicer", "amps_recc_debug_exact_slice", "amps_recc_rccl_unique_id", "amps_recc_rccl_init",
-                    "amps_recc_push_wideband_bcast") and not hasattr(L, name):
+                    "amps_recc_push_wideband_bcast", "amps_recc_drain_gather") and not hasattr(L, name):
             continue
         if name not in ("amps_recc_strerror", "amps_recc_burst_size", "amps_recc_destroy"):   # every other entry point returns int
             getattr(L, name).restype = C.c_int
@@ -367,6 +369,17 @@ class Recc:
         rc = load().amps_recc_push_wideband_bcast(self._h, ptr, int(nsamp), mem, int(root))
         if rc:
             raise AmpsError(rc, "amps_recc_push_wideband_bcast")
+
+    def drain_gather(self, root=0, cap=None):
+        """every rank in step: each drains its own list, the root returns the records of ALL ranks sorted by (channel, position)
+        (what one whole-band handle would have drained), the others an empty array"""
+        cap = cap or self.max_bursts
+        out = np.empty(cap, BURST_DTYPE)
+        nout = C.c_size_t(0)
+        rc = load().amps_recc_drain_gather(self._h, _hostptr(out), cap, C.byref(nout), int(root))
+        if rc:
+            raise AmpsError(rc, "amps_recc_drain_gather")
+        return out[:nout.value].copy()
 
     def refchain_symbols(self, iq):
         """The flow graph's own sub-chain (quadrature_demod_cf -> clock_recovery_mm_ff -> binary_slicer_fb) on the device:

@@ -864,6 +864,42 @@ int amps_recc_push_wideband_bcast(amps_recc_t *h, const float *iq, size_t nsamp,
     return rc ? rc : rc2;
 }
 
+int amps_recc_drain_gather(amps_recc_t *h, amps_recc_burst_t *out, size_t cap, size_t *nout, int root)
+{
+    if (!h || !nout) return -EINVAL;
+    *nout = 0;
+    if (!h->rccl.comm) return -ENOSYS;
+    if (root < 0 || root >= h->rccl.nranks || (h->rccl.rank == root && !out && cap)) return -EINVAL;
+    HIP_TRY(hipSetDevice(h->device));
+    // this rank's own list first; whatever it returns, the rank then takes part in the collective (the others are waiting in it) and
+    // tells them through the status word: bit 0 = its list overflowed, bit 1 = its drain failed
+    std::vector<amps_recc_burst_t> mine(h->cfg.max_bursts);
+    size_t n = 0;
+    const int lrc = amps_recc_drain(h, mine.data(), mine.size(), &n);
+    const uint32_t st = lrc == 0 ? 0u : lrc == -ENOSPC ? 1u : 2u;
+    if (st & 2u) n = 0;
+    std::vector<std::vector<uint8_t>> all;
+    uint32_t st_or = 0;
+    if (int rc = rccl_gather_records(h->rccl, mine.data(), (uint32_t)n, st, sizeof(amps_recc_burst_t), root, &all, &st_or)) return rc;
+    bool truncated = false;
+    if (h->rccl.rank == root) {
+        struct Key { uint64_t k; const amps_recc_burst_t *r; };
+        std::vector<Key> keys;
+        for (const auto &v : all) {
+            const amps_recc_burst_t *r = (const amps_recc_burst_t *)v.data();
+            for (size_t i = 0; i < v.size() / sizeof(amps_recc_burst_t); i++)
+                keys.push_back({ ((uint64_t)r[i].channel << CAPQ_POS_BITS) | (r[i].position & ((1ull << CAPQ_POS_BITS) - 1)), r + i });
+        }
+        std::sort(keys.begin(), keys.end(), [](const Key &x, const Key &y) { return x.k < y.k; });   // a channel belongs to one rank: no ties
+        const size_t k = std::min(keys.size(), cap);
+        for (size_t i = 0; i < k; i++) std::memcpy(&out[i], keys[i].r, sizeof(amps_recc_burst_t));
+        *nout = k;
+        truncated = keys.size() > cap;
+    }
+    if (st_or & 2u) return (lrc && lrc != -ENOSPC) ? lrc : -EIO;
+    return ((st_or & 1u) || truncated) ? -ENOSPC : 0;
+}
+
 int amps_recc_set_xlate(amps_recc_t *h, const amps_recc_xlate_cfg_t *x)
 {
     if (!h || !x || x->struct_size != sizeof(amps_recc_xlate_cfg_t)) return -EINVAL;

@@ -13,21 +13,25 @@
 #include <hip/hip_runtime.h>
 #include <cerrno>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
+#include <vector>
 
 namespace amps {
 
 struct RcclId { char internal[128]; };                       // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128), passed by value
 constexpr int RCCL_FLOAT32 = 7;                              // ncclFloat32 of rccl.h's ncclDataType_t
+constexpr int RCCL_UINT8 = 1;                                // ncclUint8
 
 struct RcclApi {
     void *lib = nullptr;
     int (*GetUniqueId)(RcclId *) = nullptr;
     int (*CommInitRank)(void **, int, RcclId, int) = nullptr;
     int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
-    bool ok() const { return lib && GetUniqueId && CommInitRank && Broadcast && CommDestroy; }
+    bool ok() const { return lib && GetUniqueId && CommInitRank && Broadcast && AllGather && CommDestroy; }
 };
 inline RcclApi &rccl_api()
 {
@@ -39,6 +43,7 @@ inline RcclApi &rccl_api()
             a.GetUniqueId = (int (*)(RcclId *))dlsym(a.lib, "ncclGetUniqueId");
             a.CommInitRank = (int (*)(void **, int, RcclId, int))dlsym(a.lib, "ncclCommInitRank");
             a.Broadcast = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(a.lib, "ncclBroadcast");
+            a.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(a.lib, "ncclAllGather");
             a.CommDestroy = (int (*)(void *))dlsym(a.lib, "ncclCommDestroy");
             a.GetErrorString = (const char *(*)(int))dlsym(a.lib, "ncclGetErrorString");
         }
@@ -56,6 +61,10 @@ struct RcclState {
     hipEvent_t filled[2] = { nullptr, nullptr }, freed[2] = { nullptr, nullptr };
     bool used[2] = { false, false };
     int slot = 0;
+    // record gather (rccl_gather_records): {count, status} of every rank, then the records themselves, padded to the longest list
+    uint32_t *g_hdr = nullptr;                               // device [2 + 2 nranks]: this rank's pair, then everybody's
+    uint8_t *g_send = nullptr, *g_recv = nullptr;            // device [g_cap] / [nranks g_cap] bytes
+    size_t g_cap = 0;
 };
 
 inline void rccl_destroy(RcclState &r)
@@ -67,6 +76,9 @@ inline void rccl_destroy(RcclState &r)
         if (r.filled[i]) (void)hipEventDestroy(r.filled[i]);
         if (r.freed[i]) (void)hipEventDestroy(r.freed[i]);
     }
+    if (r.g_hdr) (void)hipFree(r.g_hdr);
+    if (r.g_send) (void)hipFree(r.g_send);
+    if (r.g_recv) (void)hipFree(r.g_recv);
     if (r.cstream) (void)hipStreamDestroy(r.cstream);
     r = RcclState();
 }
@@ -138,6 +150,54 @@ inline int rccl_block_consumed(RcclState &r, int slot, hipStream_t consumer)
 {
     if (hipEventRecord(r.freed[slot], consumer) != hipSuccess) return -EIO;
     r.used[slot] = true;
+    return 0;
+}
+
+// The drained records of every rank to `root` ("ncclGather / host copy of burst records"): a few records of 728 bytes
+// per rank and drain, so the simplest collective that is in every RCCL does it -- an all-gather of {count, status}, then an
+// all-gather of the lists padded to the longest one (RCCL has no gather; grouped send / receive would save the N - 1 copies nobody
+// reads, which at these sizes are microseconds).  mine: this rank's n records of recsz bytes, host memory.  On the root: all[r] =
+// rank r's records; everywhere: status_or = the OR of the ranks' drain status words.  Blocks until the collective is through.
+inline int rccl_gather_records(RcclState &r, const void *mine, uint32_t n, uint32_t status, size_t recsz, int root,
+                               std::vector<std::vector<uint8_t>> *all, uint32_t *status_or)
+{
+    RcclApi &api = rccl_api();
+    if (!r.comm) return -ENOSYS;
+    if (root < 0 || root >= r.nranks) return -EINVAL;
+    const size_t N = (size_t)r.nranks;
+    auto fail = [&](const char *what, int rc) { std::fprintf(stderr, "amps_recc: %s: %s\n", what, api.GetErrorString ? api.GetErrorString(rc) : "error"); return -EIO; };
+    if (!r.g_hdr && hipMalloc((void **)&r.g_hdr, sizeof(uint32_t) * (2 + 2 * N)) != hipSuccess) return -ENOMEM;
+    const uint32_t pair[2] = { n, status };
+    // synchronous copies from / to pageable memory (complete on return), the collectives on the library's RCCL stream, which is idle
+    // whenever this function is entered (it ends with a synchronisation, and a broadcast in flight is waited for here)
+    if (hipStreamSynchronize(r.cstream) != hipSuccess) return -EIO;
+    if (hipMemcpy(r.g_hdr, pair, sizeof(pair), hipMemcpyHostToDevice) != hipSuccess) return -EIO;
+    if (int rc = api.AllGather(r.g_hdr, r.g_hdr + 2, sizeof(pair), RCCL_UINT8, r.comm, r.cstream)) return fail("ncclAllGather (counts)", rc);
+    if (hipStreamSynchronize(r.cstream) != hipSuccess) return -EIO;
+    std::vector<uint32_t> hdr(2 * N);
+    if (hipMemcpy(hdr.data(), r.g_hdr + 2, sizeof(uint32_t) * 2 * N, hipMemcpyDeviceToHost) != hipSuccess) return -EIO;
+    uint32_t longest = 0, st = 0;
+    for (size_t k = 0; k < N; k++) { longest = hdr[2 * k] > longest ? hdr[2 * k] : longest; st |= hdr[2 * k + 1]; }
+    *status_or = st;
+    if (all) all->assign(N, std::vector<uint8_t>());
+    if (longest == 0) return 0;                               // every rank sees the same counts: nobody enters the second collective
+    const size_t bytes = (size_t)longest * recsz;
+    if (r.g_cap < bytes) {
+        if (r.g_send) (void)hipFree(r.g_send);
+        if (r.g_recv) (void)hipFree(r.g_recv);
+        r.g_send = r.g_recv = nullptr; r.g_cap = 0;
+        if (hipMalloc((void **)&r.g_send, bytes) != hipSuccess || hipMalloc((void **)&r.g_recv, bytes * N) != hipSuccess) return -ENOMEM;
+        r.g_cap = bytes;
+    }
+    if (n && hipMemcpy(r.g_send, mine, (size_t)n * recsz, hipMemcpyHostToDevice) != hipSuccess) return -EIO;
+    if (int rc = api.AllGather(r.g_send, r.g_recv, bytes, RCCL_UINT8, r.comm, r.cstream)) return fail("ncclAllGather (records)", rc);
+    if (hipStreamSynchronize(r.cstream) != hipSuccess) return -EIO;
+    if (r.rank == root && all) {
+        for (size_t k = 0; k < N; k++) {
+            (*all)[k].resize((size_t)hdr[2 * k] * recsz);
+            if (hdr[2 * k] && hipMemcpy((*all)[k].data(), r.g_recv + k * bytes, (*all)[k].size(), hipMemcpyDeviceToHost) != hipSuccess) return -EIO;
+        }
+    }
     return 0;
 }
 

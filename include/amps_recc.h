@@ -39,7 +39,7 @@ extern "C" {
 #endif
 
 #define AMPS_RECC_ABI_VERSION 3   /* 2: amps_recc_cfg_t gained wideband_groups / wideband_group; 3: default slicer = spec D, captures track the bit
-                                     clock unless AMPS_RECC_FLAG_FIXED_TIMING, amps_recc_rccl_* / _push_wideband_bcast / _debug_exact_slice added */
+                                     clock unless AMPS_RECC_FLAG_FIXED_TIMING, amps_recc_rccl_* / _push_wideband_bcast / _drain_gather / _debug_exact_slice added */
 
 /* protocol constants of the reference */
 #define AMPS_RECC_TRIGGER_SYMS 74   /* lib/recc_impl.cc:76-77: 37 bits x 2 Manchester symbols   */
@@ -306,6 +306,13 @@ int amps_recc_debug_demod(amps_recc_t *h, const float *iq, size_t nsamp, int mem
 int amps_recc_rccl_unique_id(uint8_t id[AMPS_RECC_RCCL_ID_BYTES]);
 int amps_recc_rccl_init(amps_recc_t *h, const uint8_t id[AMPS_RECC_RCCL_ID_BYTES], int nranks, int rank);
 int amps_recc_push_wideband_bcast(amps_recc_t *h, const float *iq, size_t nsamp, int mem, int root);
+/* The collective drain that goes with it (the burst records back to one place): every rank calls it in step; each
+ * drains its own list as amps_recc_drain does (no split drain may be open) and the records of all ranks arrive at `root`, merged
+ * and sorted by (channel, position) -- what one whole-band handle would have returned.  The other ranks get *nout = 0 and may pass
+ * out = NULL, cap = 0.  -ENOSPC on every rank if any rank's list overflowed max_bursts (and on the root if cap is too small; what
+ * fits is returned), -EIO (or the rank's own error) on every rank if any rank's drain failed: a rank never leaves the others
+ * waiting in the collective.  Two small ncclAllGather calls ({count, status}, then the lists padded to the longest). */
+int amps_recc_drain_gather(amps_recc_t *h, amps_recc_burst_t *out, size_t cap, size_t *nout, int root);
 
 /* test tap of slicer spec D's bit logic, evaluated ON THE HOST by the very functions the kernels inline (no device needed):
  *   form 0: the streaming kernel's 32-sample window, oldest sample at bit 0: in = {SX, ST, SC}; out[0] = the slicer bits, exact from bit

@@ -1,4 +1,4 @@
-"""-m gpu: RCCL inside the C ABI (amps_recc_rccl_unique_id / _rccl_init / _push_wideband_bcast, include/amps_recc.h) -- the entry a
+"""-m gpu: RCCL inside the C ABI (amps_recc_rccl_unique_id / _rccl_init / _push_wideband_bcast / _drain_gather, include/amps_recc.h) -- the entry a
 flow graph uses to run one band over the GPUs of a node.  A box has one GPU, so the communicator has ONE rank here (RCCL refuses two
 ranks on a device): ncclCommInitRank, ncclBroadcast into the two receive buffers, the event ordering against the handle's
 stream and the push behind it all run; the records must be those of a plain amps_recc_push_wideband of the same stream."""
@@ -39,9 +39,21 @@ def test_broadcast_push_equals_plain_push(gpu):
     assert got.tobytes() == want.tobytes()
     # the same with HOST blocks at the root (what gr::amps::recc_wideband::set_rccl feeds it): staged by the library
     with capi.Recc(n_channels=CW, sps=3, max_samples=n // D + 72, max_bursts=64, wideband=WB) as r:
+        with pytest.raises(capi.AmpsError):                      # the collective drain needs the communicator too
+            r.drain_gather()
         r.rccl_init(capi.Recc.rccl_unique_id(), 1, 0)
+        assert len(r.drain_gather(root=0)) == 0                  # nothing yet: the count exchange alone
         for p in parts + [np.zeros(64 * D, np.complex64)]:
             r.push_wideband_bcast(p, len(p), root=0)
-        assert r.drain().tobytes() == want.tobytes()
+        # amps_recc_drain_gather: the ranks' records merged at the root (here: the one rank's own list through both all-gathers)
+        assert r.drain_gather(root=0).tobytes() == want.tobytes()
+        assert len(r.drain_gather(root=0)) == 0
+        with pytest.raises(capi.AmpsError):
+            r.drain_gather(root=1)                               # not a rank of this communicator
+        for p in parts + [np.zeros(64 * D, np.complex64)]:       # a list longer than the caller's buffer: what fits, and -ENOSPC
+            r.push_wideband_bcast(p, len(p), root=0)
+        with pytest.raises(capi.AmpsError) as ei:
+            r.drain_gather(root=0, cap=2)
+        assert ei.value.code == -28
     for (k, off), (kind, min10, esn, dialed, words) in truth.items():
         assert any(g["min"].decode() == min10 and g["valid"].all() for g in got)
