@@ -136,12 +136,14 @@ static void capture(orc_fused_t *f, uint64_t nc, amps_recc_burst_t *out)
         const int nb = b == 0 ? AMPS_RECC_TRIGGER_SYMS / 2 : b == 1 ? 7 + AMPS_RECC_WORD_BITS : AMPS_RECC_WORD_BITS;
         int E[2] = { 0, 0 }, n[2] = { 0, 0 };
         for (int k = k0; k < k0 + nb; k++) {
-            const uint64_t ta = (uint64_t)((int64_t)nc + (int64_t)sps * (2 * k + 1) + dly);
-            const int a = f->g[ta], bb = f->g[ta + sps];
+            /* (samples in front of the stream read 1, as they do in the trigger test: only a TOLERANT match can begin there -- the
+             * trigger's first symbol is 0 -- and then only block 0, which is measured and not captured, looks at them) */
+            const int64_t ta = (int64_t)nc + (int64_t)sps * (2 * k + 1) + dly;
+            const int a = gbit(f, ta), bb = gbit(f, ta + sps);
             if (k >= 0) { burst[2 * k] = (uint8_t)a; burst[2 * k + 1] = (uint8_t)bb; }
             if (f->track && a != bb) {
                 int cnt = 0;
-                for (int m = 1; m < sps; m++) cnt += f->g[ta + m] == a;
+                for (int m = 1; m < sps; m++) cnt += gbit(f, ta + m) == a;
                 E[a] += 2 * cnt - (sps - 1);
                 n[a]++;
             }
