@@ -869,7 +869,8 @@ int amps_recc_drain_gather(amps_recc_t *h, amps_recc_burst_t *out, size_t cap, s
     if (!h || !nout) return -EINVAL;
     *nout = 0;
     if (!h->rccl.comm) return -ENOSYS;
-    if (root < 0 || root >= h->rccl.nranks || (h->rccl.rank == root && !out && cap)) return -EINVAL;
+    if (root < 0 || root >= h->rccl.nranks) return -EINVAL;      // (the same verdict on every rank: nobody is left alone in the collective)
+    if (!out) cap = 0;
     HIP_TRY(hipSetDevice(h->device));
     // this rank's own list first; whatever it returns, the rank then takes part in the collective (the others are waiting in it) and
     // tells them through the status word: bit 0 = its list overflowed, bit 1 = its drain failed
