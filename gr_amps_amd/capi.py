@@ -77,6 +77,17 @@ class XlateCfg(C.Structure):
     ]
 
 
+class RcclInfo(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("alive", C.c_int32), ("nranks", C.c_int32), ("rank", C.c_int32),
+        ("comm_nranks", C.c_int32), ("comm_rank", C.c_int32), ("device", C.c_int32),
+        ("pci_domain", C.c_int32), ("pci_bus", C.c_int32), ("pci_device", C.c_int32),
+        ("device_uuid", C.c_uint8 * 16), ("max_samples_per_push", C.c_uint64), ("max_bursts_per_gather", C.c_uint32),
+        ("timeout_ms", C.c_uint32), ("collectives_timed", C.c_uint64), ("collective_ms", C.c_double),
+        ("collective_bytes", C.c_uint64), ("last_mode", C.c_int32), ("_pad", C.c_int32), ("library", C.c_char * 96),
+    ]
+
+
 class Reply(C.Structure):
     _fields_ = [
         ("has_focc", C.c_uint8), ("focc_stream", C.c_int32), ("focc_nwords", C.c_int32),
@@ -99,7 +110,11 @@ EXPORTS = (
     "amps_recc_wait_event", "amps_recc_record_event", "amps_recc_refchain_symbols", "amps_recc_refchain_tables",
     "amps_recc_drain_bursts", "amps_recc_default_slicer", "amps_recc_debug_exact_slice",
     "amps_recc_rccl_unique_id", "amps_recc_rccl_init", "amps_recc_push_wideband_bcast", "amps_recc_drain_gather",
+    "amps_recc_push_wideband_dist", "amps_recc_rccl_info", "amps_recc_rccl_abort", "amps_recc_rccl_set_timeout",
 )
+_NEW_IN_ABI4 = ("amps_recc_push_wideband_dist", "amps_recc_rccl_info", "amps_recc_rccl_abort", "amps_recc_rccl_set_timeout")
+DIST_BROADCAST, DIST_SCATTER_ALLGATHER = 0, 1
+DIST_MODES = {"broadcast": DIST_BROADCAST, "scatter_allgather": DIST_SCATTER_ALLGATHER, 0: 0, 1: 1}
 
 _lib = None
 
@@ -142,6 +157,11 @@ def load():
         L.amps_recc_push_wideband_bcast.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int]
     if hasattr(L, "amps_recc_drain_gather"):
         L.amps_recc_drain_gather.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.c_int]
+    if hasattr(L, "amps_recc_push_wideband_dist"):
+        L.amps_recc_push_wideband_dist.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
+        L.amps_recc_rccl_info.argtypes = [vp, C.POINTER(RcclInfo)]
+        L.amps_recc_rccl_abort.argtypes = [vp]
+        L.amps_recc_rccl_set_timeout.argtypes = [vp, C.c_uint32]
     L.amps_recc_drain.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.amps_recc_refchain_symbols.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, vp, C.c_size_t, vp]
     L.amps_recc_refchain_tables.argtypes = [vp, vp, vp]
@@ -162,7 +182,7 @@ def load():
     L.amps_bch_decode_words.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, vp, vp, vp]
     for name in EXPORTS:
         if name in ("amps_recc_default_slicer", "amps_recc_debug_exact_slice", "amps_recc_rccl_unique_id", "amps_recc_rccl_init",
-                    "amps_recc_push_wideband_bcast", "amps_recc_drain_gather") and not hasattr(L, name):
+                    "amps_recc_push_wideband_bcast", "amps_recc_drain_gather") + _NEW_IN_ABI4 and not hasattr(L, name):
             continue
         if name not in ("amps_recc_strerror", "amps_recc_burst_size", "amps_recc_destroy"):   # every other entry point returns int
             getattr(L, name).restype = C.c_int
@@ -359,16 +379,52 @@ class Recc:
         if rc:
             raise AmpsError(rc, "amps_recc_rccl_init")
 
-    def push_wideband_bcast(self, iq, nsamp, root=0):
-        """every rank in step; the root passes its block (a CUDA tensor, used in place, or a numpy array, staged), the others None"""
-        ptr, mem = None, MEM_DEVICE
+    def push_wideband_dist(self, iq, nsamp=None, root=0, mode="broadcast"):
+        """every rank in step; the root passes its block (a CUDA tensor, used in place, or a numpy array, staged), the others None.
+        mode: "broadcast" (flat ncclBroadcast) or "scatter_allgather".  Returns the number of samples pushed: the ROOT's, on every rank."""
+        ptr, mem, n = None, MEM_DEVICE, 0
         if iq is not None:
             if isinstance(iq, np.ndarray):
                 iq = np.ascontiguousarray(iq, np.complex64).reshape(-1)
+            have = int(iq.numel()) if hasattr(iq, "numel") else int(iq.size)      # complex samples
+            n = have if nsamp is None else int(nsamp)
+            if n > have:                                   # the C side would read past the end of the buffer
+                raise ValueError("nsamp = %d exceeds the %d complex samples of the block" % (n, have))
             ptr, mem, keep = _as_ptr(iq, self.sync_torch)
-        rc = load().amps_recc_push_wideband_bcast(self._h, ptr, int(nsamp), mem, int(root))
+        pushed = C.c_size_t(0)
+        rc = load().amps_recc_push_wideband_dist(self._h, ptr, n, mem, int(root), DIST_MODES[mode], C.byref(pushed))
         if rc:
-            raise AmpsError(rc, "amps_recc_push_wideband_bcast")
+            raise AmpsError(rc, "amps_recc_push_wideband_dist")
+        return int(pushed.value)
+
+    def push_wideband_bcast(self, iq, nsamp=None, root=0):
+        """push_wideband_dist(mode="broadcast"): the round-4 entry point"""
+        return self.push_wideband_dist(iq, nsamp, root, "broadcast")
+
+    def rccl_abort(self):
+        """this rank leaves: its communicator is aborted, the peers' bounded waits end with -ETIMEDOUT"""
+        rc = load().amps_recc_rccl_abort(self._h)
+        if rc:
+            raise AmpsError(rc, "amps_recc_rccl_abort")
+
+    def rccl_set_timeout(self, milliseconds):
+        rc = load().amps_recc_rccl_set_timeout(self._h, int(milliseconds))
+        if rc:
+            raise AmpsError(rc, "amps_recc_rccl_set_timeout")
+
+    def rccl_info(self):
+        """the communicator as RCCL reports it + the device it runs on + the timed data collectives, as a dict"""
+        info = RcclInfo()
+        info.struct_size = C.sizeof(RcclInfo)
+        rc = load().amps_recc_rccl_info(self._h, C.byref(info))
+        if rc:
+            raise AmpsError(rc, "amps_recc_rccl_info")
+        d = {k: getattr(info, k) for k, _ in RcclInfo._fields_ if k not in ("struct_size", "_pad", "device_uuid", "library")}
+        d["device_uuid"] = bytes(info.device_uuid).hex()
+        d["library"] = info.library.decode(errors="replace")
+        d["last_mode"] = {0: "broadcast", 1: "scatter_allgather"}.get(info.last_mode)
+        d["collective_gbps"] = (info.collective_bytes / (info.collective_ms * 1e-3) / 1e9) if info.collective_ms > 0 else None
+        return d
 
     def drain_gather(self, root=0, cap=None):
         """every rank in step: each drains its own list, the root returns the records of ALL ranks sorted by (channel, position)

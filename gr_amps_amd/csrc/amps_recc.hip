@@ -476,6 +476,10 @@ const char *amps_recc_strerror(int code)
     case E2BIG: return "push larger than the configured capacity";
     case EOVERFLOW: return "trigger-hit list overflowed";
     case ENOSYS: return "seam not configured on this handle";
+    case EBUSY: return "busy: a split drain is open, the stream has started, or the handle already has a communicator";
+    case ETIMEDOUT: return "no answer from the other ranks within the RCCL timeout: communicator aborted";
+    case ENOTCONN: return "the handle's communicator has been aborted";
+    case EREMOTEIO: return "another rank reported an error: no rank ran the collective";
     default: return "unknown error";
     }
 }
@@ -847,31 +851,100 @@ int amps_recc_rccl_init(amps_recc_t *h, const uint8_t *id, int nranks, int rank)
     if (!h) return -EINVAL;
     if (!h->chz.enabled) return -ENOSYS;
     HIP_TRY(hipSetDevice(h->device));
-    return rccl_init(h->rccl, id, nranks, rank);
+    RcclLocal loc;
+    loc.groups = h->cfg.wideband_groups >= 2 ? h->cfg.wideband_groups : 0;
+    loc.group = h->cfg.wideband_group;
+    // the largest block one push takes: max_samples_per_push frames of 512 samples (amps_recc_push_wideband: -E2BIG beyond)
+    loc.cap_samples = (uint64_t)h->cfg.max_samples_per_push * CHZ_D;
+    loc.max_bursts = h->cfg.max_bursts;
+    const int rc = rccl_init(h->rccl, id, nranks, rank, loc, sizeof(amps_recc_burst_t));
+    if (rc == 0) h->rccl.timing = h->timing;
+    return rc;
+}
+
+int amps_recc_rccl_set_timeout(amps_recc_t *h, uint32_t milliseconds)
+{
+    if (!h || milliseconds == 0) return -EINVAL;
+    h->rccl.timeout_ms = milliseconds;
+    return 0;
+}
+
+int amps_recc_rccl_abort(amps_recc_t *h)
+{
+    if (!h) return -EINVAL;
+    if (!h->rccl.comm) return h->rccl.dead ? 0 : -ENOSYS;
+    HIP_TRY(hipSetDevice(h->device));
+    rccl_kill(h->rccl);
+    return 0;
+}
+
+int amps_recc_rccl_info(amps_recc_t *h, amps_recc_rccl_info_t *info)
+{
+    if (!h || !info || info->struct_size != sizeof(amps_recc_rccl_info_t)) return -EINVAL;
+    RcclState &r = h->rccl;                                   // (no communicator yet: nranks = 0, the device fields are still filled)
+    HIP_TRY(hipSetDevice(h->device));
+    std::memset((char *)info + sizeof(info->struct_size), 0, sizeof(*info) - sizeof(info->struct_size));
+    info->alive = r.comm ? 1 : 0;
+    info->nranks = r.nranks; info->rank = r.rank;
+    info->comm_nranks = -1; info->comm_rank = -1;
+    RcclApi &api = rccl_api();
+    if (r.comm && api.CommCount) { int v = -1; if (api.CommCount(r.comm, &v) == 0) info->comm_nranks = v; }
+    if (r.comm && api.CommUserRank) { int v = -1; if (api.CommUserRank(r.comm, &v) == 0) info->comm_rank = v; }
+    info->device = h->device;
+    info->max_samples_per_push = r.cap_common;
+    info->max_bursts_per_gather = r.mb_common;
+    info->timeout_ms = r.timeout_ms;
+    if (r.comm) for (int i = 0; i < 2; i++) rccl_harvest(r, i, true);
+    info->collectives_timed = r.coll_count;
+    info->collective_ms = r.coll_ms;
+    info->collective_bytes = r.coll_count ? r.coll_bytes : 0;
+    info->last_mode = r.last_mode;
+    std::snprintf(info->library, sizeof(info->library), "%s", api.path);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) {
+        static_assert(sizeof(info->device_uuid) == sizeof(prop.uuid.bytes), "uuid");
+        std::memcpy(info->device_uuid, prop.uuid.bytes, sizeof(info->device_uuid));
+        info->pci_bus = prop.pciBusID; info->pci_device = prop.pciDeviceID; info->pci_domain = prop.pciDomainID;
+    }
+    return 0;
+}
+
+int amps_recc_push_wideband_dist(amps_recc_t *h, const float *iq, size_t nsamp, int mem, int root, int mode, size_t *npushed)
+{
+    if (npushed) *npushed = 0;
+    if (!h) return -EINVAL;
+    if (h->rccl.dead) return -ENOTCONN;
+    if (!h->chz.enabled || !h->rccl.comm) return -ENOSYS;
+    HIP_TRY(hipSetDevice(h->device));
+    const float2 *blk = nullptr;
+    int slot = 0;
+    size_t n = 0;
+    // (a missing block or nsamp = 0 at the root is the root's error and travels through the header: the other ranks learn of it)
+    if (int rc = rccl_distribute(h->rccl, (const float2 *)iq, mem == AMPS_MEM_HOST, nsamp, root, mode, h->stream, &blk, &slot, &n)) return rc;
+    const int rc = amps_recc_push_wideband(h, (const float *)blk, n, AMPS_MEM_DEVICE);
+    const int rc2 = rccl_block_consumed(h->rccl, slot, h->stream);
+    if (npushed) *npushed = n;
+    return rc ? rc : rc2;
 }
 
 int amps_recc_push_wideband_bcast(amps_recc_t *h, const float *iq, size_t nsamp, int mem, int root)
 {
-    if (!h) return -EINVAL;
-    if (!h->chz.enabled || !h->rccl.comm) return -ENOSYS;
-    if (nsamp == 0) return -EINVAL;                           // a collective: every rank must issue the same, non-empty, broadcast
-    HIP_TRY(hipSetDevice(h->device));
-    const float2 *blk = nullptr;
-    int slot = 0;
-    if (int rc = rccl_broadcast_block(h->rccl, (const float2 *)iq, mem == AMPS_MEM_HOST, nsamp, root, h->stream, &blk, &slot)) return rc;
-    const int rc = amps_recc_push_wideband(h, (const float *)blk, nsamp, AMPS_MEM_DEVICE);
-    const int rc2 = rccl_block_consumed(h->rccl, slot, h->stream);
-    return rc ? rc : rc2;
+    return amps_recc_push_wideband_dist(h, iq, nsamp, mem, root, AMPS_RECC_DIST_BROADCAST, nullptr);
 }
 
 int amps_recc_drain_gather(amps_recc_t *h, amps_recc_burst_t *out, size_t cap, size_t *nout, int root)
 {
     if (!h || !nout) return -EINVAL;
     *nout = 0;
+    if (h->rccl.dead) return -ENOTCONN;
     if (!h->rccl.comm) return -ENOSYS;
     if (root < 0 || root >= h->rccl.nranks) return -EINVAL;      // (the same verdict on every rank: nobody is left alone in the collective)
     if (!out) cap = 0;
     HIP_TRY(hipSetDevice(h->device));
+    // The handle's kernels wait for the data collectives: if a peer has gone, they never start, and an unbounded drain would sit behind
+    // them for ever.  So the wait for the stream is bounded here (then the drain below finds it idle); on expiry the communicator is
+    // aborted and the peers run into their own bound.
+    if (int rc = rccl_wait(h->rccl, h->stream)) return rc;
     // this rank's own list first; whatever it returns, the rank then takes part in the collective (the others are waiting in it) and
     // tells them through the status word: bit 0 = its list overflowed, bit 1 = its drain failed
     std::vector<amps_recc_burst_t> mine(h->cfg.max_bursts);
@@ -1211,6 +1284,7 @@ int amps_recc_set_timing(amps_recc_t *h, int mode)
     collect_spans(h);
     h->timing_mode = mode;
     h->timing = mode != AMPS_RECC_TIMING_OFF;
+    h->rccl.timing = h->timing;
     return 0;
 }
 

@@ -340,13 +340,18 @@ __device__ __forceinline__ void manchester_from_ring(DecodeCore &s, const uint64
         if (rhs > 0) dly += lhs > rhs ? 1 : lhs < -rhs ? -1 : 0;
     };
     // ---- block 0: the 37 bits of the trigger, in front of the capture: measured only.  A trigger at the very start of a stream
-    // would put lane 0's early bit in front of the ring window: that lane fetches from bit 0 and skips its (unused) early bit
+    // puts the window of the leading lanes (partly) in front of the stream: an exact trigger by the one early bit of lane 0, which
+    // is not used; a TOLERANT one (cfg.sync_tolerance) by up to its tolerated symbols.  What lies in front of the stream reads 1,
+    // as in the trigger test and in the CPU model (gbit() of oracle/fused_model.c): s = the number of window bits in front of bit 0
+    // (s > 0 used to read stream bit 0 unshifted)
     {
         const int k = -TRACK_PRE_BITS + lane;
         const bool on = lane < TRACK_PRE_BITS;
         const int32_t nas = base + (int32_t)sps * (2 * k + 1) - 1;
         const uint32_t na = nas < 0 ? 0u : (uint32_t)nas, q = on ? na >> 5 : 0u;
-        const uint32_t w = (nas < 0 ? r32[q] << 1 : __builtin_amdgcn_alignbit(r32[q + 1], r32[q], na & 31u)) >> 1;
+        const int32_t sh = -nas - 1;                                  // >= 0 where the window starts at or before bit 0
+        const uint32_t w = nas >= 0 ? __builtin_amdgcn_alignbit(r32[q + 1], r32[q], na & 31u) >> 1
+                                    : sh >= 32 ? ~0u : ((r32[0] << (uint32_t)sh) | ((1u << (uint32_t)sh) - 1u));
         fetch(lane, 0, lane < 7 + AMPS_RECC_WORD_BITS);           // block 1 = bits 0 .. 54
         if (lane == 0 && keep_delays) s.dly[0] = 0;
         if (track) measure(w, on);

@@ -123,6 +123,23 @@ __device__ __forceinline__ void capture_store_wave(const ResolveArgs &a, uint64_
 // DONE_GROUPS group counters (channel mod DONE_GROUPS) and only the last of a group steps the top counter; and a workgroup reserves
 // the record slots of a whole batch of captures with one atomic, issued behind the first ring loads and consumed after the decode.
 constexpr uint32_t DONE_GROUPS = 32;       // done_blocks[0] = top counter, [1 + g] = group g
+// A workgroup counts itself done.  The last one reads `nrecords` and publishes it to the host header; what that value must contain is
+// every workgroup's slot reservation (a device-scope atomic on nrecords issued before its done-count).  Relaxed atomics leave that to
+// where the hardware performs device-scope atomics (in order at the memory side of the L2s; cross-checked by
+// AMPS_RECC_CHECK_HEADER); release on the counting side + acquire on the reading side make it a guarantee of the memory model: the
+// reservation happens-before the last workgroup's read (ADVICE r03 / VERDICT r04 item 6).  The release waits for the counting WAVE's
+// earlier stores only (s_waitcnt + L2 write-back, no device-wide fence).  -DAMPS_RESOLVE_DONE_ACQREL=0 restores the relaxed form (A/B).
+#ifndef AMPS_RESOLVE_DONE_ACQREL
+#define AMPS_RESOLVE_DONE_ACQREL 1
+#endif
+__device__ __forceinline__ uint32_t count_done(uint32_t *p)
+{
+#if AMPS_RESOLVE_DONE_ACQREL
+    return __hip_atomic_fetch_add(p, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    return atomicAdd(p, 1u);
+#endif
+}
 
 constexpr int RESOLVE_THREADS = 256;       // many channels, few segments each
 constexpr int RESOLVE_THREADS_WIDE = 1024; // few channels, thousands of segments each (one channel x 2^26 samples)
@@ -290,9 +307,9 @@ __global__ __launch_bounds__(THREADS, 4) void recc_resolve_kernel(ResolveArgs a)
         const uint32_t ng = gridDim.x < DONE_GROUPS ? gridDim.x : DONE_GROUPS;
         const uint32_t g = blockIdx.x % DONE_GROUPS;
         const uint32_t gsize = (gridDim.x - g + DONE_GROUPS - 1) / DONE_GROUPS;
-        if (atomicAdd(a.done_blocks + 1 + g, 1u) == gsize - 1) {
+        if (count_done(a.done_blocks + 1 + g) == gsize - 1) {
             atomicExch(a.done_blocks + 1 + g, 0u);
-            if (atomicAdd(a.done_blocks, 1u) == ng - 1) {
+            if (count_done(a.done_blocks) == ng - 1) {
                 a.hdr_host[0] = atomicAdd(a.nrecords, 0u);
                 a.hdr_host[1] = atomicOr(a.status, 0u);
                 atomicExch(a.done_blocks, 0u);
@@ -329,7 +346,7 @@ __global__ __launch_bounds__(64) void recc_capture_kernel(ResolveArgs a)
     // take part
     const uint32_t nb = ncap < gridDim.x ? (ncap ? ncap : 1u) : gridDim.x;
     if (lane == 0 && blockIdx.x < nb) {
-        const uint32_t t = atomicAdd(a.done_blocks, 1u);
+        const uint32_t t = count_done(a.done_blocks);
         if (t == nb - 1) {
             a.hdr_host[0] = atomicAdd(a.nrecords, 0u);
             a.hdr_host[1] = atomicOr(a.status, 0u);

@@ -7,6 +7,11 @@
 //                                      every line is prefixed with the channel the burst came from
 //   recctest wide <file.fc32> [chunk] [slicer]  one 30.72 Msps wideband capture -> gr::amps::recc_wideband (832 channels from bin 96); every
 //                                      burst's lines are prefixed with its channel; decoded through the "bursts" port
+//   recctest widerank <file.fc32> <chunk> <idfile> <nranks> <rank> [mode]   ONE rank of the same band over `nranks` processes (2, 4 or 8; one per GPU of a
+//                                      node): gr::amps::recc_wideband::make(832, 96, -1, nranks, rank) + set_rccl -- rank 0 owns the capture and the
+//                                      library distributes it (mode 0 = ncclBroadcast, 1 = scatter + all-gather); the other ranks' items only pace
+//                                      them (they may use any chunk).  The 128-byte communicator id travels through <idfile> (rank 0 writes it).
+//                                      Each rank prints the bursts of ITS channel group; the union is what `recctest wide` prints
 //   recctest raw  <file.fc32> [chunk] [center_hz]   the flow graph's own capture format (grc/recctest.grc:591): 400 ksps fc32,
 //                                      channel at center_hz (default +160 kHz, :889-937) -> channel filter + fused chain on the GPU
 // Every message published on recc_decode's output ports is printed as one text line, which is what
@@ -22,6 +27,8 @@
 #include <fstream>
 #include <iterator>
 #include <string>
+#include <thread>
+#include <chrono>
 #include <vector>
 
 static std::string bits(const pmt::pmt_t &blob)
@@ -105,8 +112,30 @@ int main(int argc, char **argv)
                 for (int c = 0; c < C; c++) ins.push_back(chans[c].data() + off);
                 if (src->work(n, ins, outs) != 0) return 1;
             }
-        } else if (mode == "wide") {
-            auto src = gr::amps::recc_wideband::make(832, 96, argc > 4 ? std::atoi(argv[4]) : -1);
+        } else if (mode == "wide" || mode == "widerank") {
+            const bool ranks = mode == "widerank";
+            if (ranks && argc < 7) { std::fprintf(stderr, "usage: %s widerank <file> <chunk> <idfile> <nranks> <rank> [mode]\n", argv[0]); return 2; }
+            const int nranks = ranks ? std::atoi(argv[5]) : 0, rank = ranks ? std::atoi(argv[6]) : 0;
+            auto src = ranks ? gr::amps::recc_wideband::make(832, 96, -1, nranks, rank) : gr::amps::recc_wideband::make(832, 96, argc > 4 ? std::atoi(argv[4]) : -1);
+            if (ranks) {
+                // the control plane is the application's: here, a file
+                std::string id;
+                const std::string idfile = argv[4];
+                if (rank == 0) {
+                    id = gr::amps::recc_wideband::rccl_unique_id();
+                    std::ofstream o(idfile + ".tmp", std::ios::binary);
+                    o.write(id.data(), (std::streamsize)id.size());
+                    o.close();
+                    std::rename((idfile + ".tmp").c_str(), idfile.c_str());
+                } else {
+                    for (int tries = 0; tries < 12000 && id.size() != 128; tries++) {
+                        std::ifstream i(idfile, std::ios::binary);
+                        if (i) id.assign((std::istreambuf_iterator<char>(i)), std::istreambuf_iterator<char>());
+                        if (id.size() != 128) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+                    }
+                }
+                src->set_rccl(id, nranks, rank, 0, argc > 7 ? std::atoi(argv[7]) : 0);
+            }
             struct demux : gr::block {
                 std::shared_ptr<gr::basic_block> dec;
                 demux() : gr::block("demux", gr::io_signature::make(0, 0, 0), gr::io_signature::make(0, 0, 0))

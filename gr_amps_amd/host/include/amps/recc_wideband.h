@@ -23,10 +23,16 @@ public:
     //         include/amps_recc.h; channel numbers on the ports stay whole-band numbers.
     static sptr make(int n_channels = 832, int first_bin = 96, int slicer = -1, int groups = 0, int group = 0);
     // Let ONE rank own the stream: after this call (a collective over all `nranks` blocks; `id` = the 128 bytes one of them got from
-    // rccl_unique_id(), carried between the processes by the application) work() broadcasts rank `root`'s input over xGMI with RCCL
-    // inside amps_recc_push_wideband_bcast; the other ranks' input only paces their flow graphs (same item counts: e.g. a null
-    // source behind the same throttle) and is ignored.
-    virtual void set_rccl(const std::string &id, int nranks, int rank, int root = 0) = 0;
+    // rccl_unique_id(), carried between the processes by the application) work() distributes rank `root`'s input over xGMI with RCCL
+    // inside amps_recc_push_wideband_dist (mode 0 = flat broadcast, 1 = scatter + all-gather: AMPS_RECC_DIST_*).  The other ranks'
+    // input only paces their flow graphs and is ignored -- INCLUDING ITS ITEM COUNTS: GNU Radio's schedulers in different processes do
+    // not hand out the same noutput_items sequence, so the block never puts its own count into a collective.  The root cuts its input
+    // into blocks of at most 2^22 samples, one collective per block, each carrying its size in the library's header; the ranks stay in
+    // step by STREAM POSITION: a non-root rank joins collectives -- of whatever size the root announces -- until the root's stream has
+    // covered the items its own pacing input has offered (feed it a null source behind a throttle at the root's sample rate).
+    // A rank whose push or drain fails aborts its communicator before it returns WORK_DONE
+    // (amps_recc_rccl_abort): its peers' bounded waits then end with -ETIMEDOUT instead of never.
+    virtual void set_rccl(const std::string &id, int nranks, int rank, int root = 0, int mode = 0) = 0;
     static std::string rccl_unique_id();
 };
 

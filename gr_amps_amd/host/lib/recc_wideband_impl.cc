@@ -17,7 +17,8 @@ class recc_wideband_impl : public recc_wideband {
     static const int kMaxPush = 1 << 22;          // wideband samples per push (8192 frames)
     static const int kMaxRecs = 4096;
     bool d_bcast = false;                          // set_rccl: the stream comes from rank d_root by RCCL
-    int d_root = 0, d_rank = 0;
+    int d_root = 0, d_rank = 0, d_mode = AMPS_RECC_DIST_BROADCAST;
+    unsigned long long d_stream_samples = 0, d_paced_items = 0;   // non-root ranks: samples the root has distributed / items this rank's pacing input has offered
 
 public:
     recc_wideband_impl(int C, int first_bin, int slicer, int groups, int group)
@@ -46,37 +47,67 @@ public:
     }
     ~recc_wideband_impl() { amps_recc_destroy(d_handle); }
 
-    void set_rccl(const std::string &id, int nranks, int rank, int root)
+    void set_rccl(const std::string &id, int nranks, int rank, int root, int mode)
     {
         if (id.size() != AMPS_RECC_RCCL_ID_BYTES) throw std::runtime_error("amps::recc_wideband: the RCCL id is 128 bytes");
+        if (mode != AMPS_RECC_DIST_BROADCAST && mode != AMPS_RECC_DIST_SCATTER_ALLGATHER) throw std::runtime_error("amps::recc_wideband: unknown distribution mode");
         int rc = amps_recc_rccl_init(d_handle, (const uint8_t *)id.data(), nranks, rank);
         if (rc != 0) throw std::runtime_error(std::string("amps::recc_wideband: rccl: ") + amps_recc_strerror(rc));
-        d_bcast = true; d_root = root; d_rank = rank;
+        d_bcast = true; d_root = root; d_rank = rank; d_mode = mode;
+    }
+
+    // one block through the seam (alone, or as this rank's part of one collective) + its records out on the ports; false = stop the flow graph
+    bool push_and_publish(const float *in, size_t n)
+    {
+        int rc;
+        size_t pushed = n;
+        if (d_bcast) {
+            // every rank in step, ONE collective per call; only the root's items are read (staged to the device by the library) and only
+            // the root's n counts -- it travels in the header of the collective (the schedulers of the ranks' flow graphs do not agree on
+            // noutput_items)
+            const bool root = d_rank == d_root;
+            rc = amps_recc_push_wideband_dist(d_handle, root ? in : nullptr, root ? n : 0, AMPS_MEM_HOST, d_root, d_mode, &pushed);
+            d_stream_samples += pushed;
+        } else rc = amps_recc_push_wideband(d_handle, in, n, AMPS_MEM_HOST);
+        if (rc != 0) { std::fprintf(stderr, "amps::recc_wideband: %s\n", amps_recc_strerror(rc)); return leave(); }
+        size_t nrec = 0;
+        rc = amps_recc_drain_bursts(d_handle, d_recs.data(), d_bursts.data(), kMaxRecs, &nrec);
+        // -ENOSPC: more bursts than the list holds were found; the ones that fit are returned and the list recovers on the
+        // next push -- a recoverable condition must not end the flow graph
+        if (rc == -ENOSPC) std::fprintf(stderr, "amps::recc_wideband: %s (bursts dropped, continuing)\n", amps_recc_strerror(rc));
+        else if (rc != 0) { std::fprintf(stderr, "amps::recc_wideband: %s\n", amps_recc_strerror(rc)); return leave(); }
+        for (size_t i = 0; i < nrec; i++) {
+            const pmt::pmt_t ch = pmt::from_long((long)d_recs[i].channel);
+            message_port_pub(pmt::mp("bursts"), pmt::cons(ch, pmt::mp(d_bursts.data() + i * AMPS_RECC_CAPTURE_SYMS, AMPS_RECC_CAPTURE_SYMS)));
+            message_port_pub(pmt::mp("records"), pmt::cons(ch, pmt::mp(&d_recs[i], sizeof(d_recs[i]))));
+        }
+        return true;
+    }
+    // this rank stops: the others must not wait for it beyond their bound
+    bool leave()
+    {
+        if (d_bcast) (void)amps_recc_rccl_abort(d_handle);
+        return false;
     }
 
     int work(int noutput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &)
     {
         const float *in = (const float *)input_items[0];
+        if (d_bcast && d_rank != d_root) {
+            // A non-root rank: its items are pacing only.  The ranks stay in step by STREAM POSITION, not by call or item counts (which
+            // the schedulers of different processes do not share): this rank joins collectives -- each of whatever size the root
+            // announces in its header -- until the root's stream has covered the items its own pacing input has offered so far.
+            d_paced_items += (unsigned long long)noutput_items;
+            while (d_stream_samples < d_paced_items)
+                if (!push_and_publish(nullptr, 0)) return WORK_DONE;
+            consume_each(noutput_items);
+            return 0;
+        }
         int done = 0;
         while (done < noutput_items) {
             int n = noutput_items - done;
             if (n > kMaxPush) n = kMaxPush;
-            int rc;
-            if (d_bcast)                            // every rank in step; only the root's items are read (staged to the device by the library)
-                rc = amps_recc_push_wideband_bcast(d_handle, d_rank == d_root ? in + 2 * (size_t)done : nullptr, (size_t)n, AMPS_MEM_HOST, d_root);
-            else rc = amps_recc_push_wideband(d_handle, in + 2 * (size_t)done, (size_t)n, AMPS_MEM_HOST);
-            if (rc != 0) { std::fprintf(stderr, "amps::recc_wideband: %s\n", amps_recc_strerror(rc)); return WORK_DONE; }
-            size_t nrec = 0;
-            rc = amps_recc_drain_bursts(d_handle, d_recs.data(), d_bursts.data(), kMaxRecs, &nrec);
-            // -ENOSPC: more bursts than the list holds were found; the ones that fit are returned and the list recovers on the
-            // next push -- a recoverable condition must not end the flow graph
-            if (rc == -ENOSPC) std::fprintf(stderr, "amps::recc_wideband: %s (bursts dropped, continuing)\n", amps_recc_strerror(rc));
-            else if (rc != 0) { std::fprintf(stderr, "amps::recc_wideband: %s\n", amps_recc_strerror(rc)); return WORK_DONE; }
-            for (size_t i = 0; i < nrec; i++) {
-                const pmt::pmt_t ch = pmt::from_long((long)d_recs[i].channel);
-                message_port_pub(pmt::mp("bursts"), pmt::cons(ch, pmt::mp(d_bursts.data() + i * AMPS_RECC_CAPTURE_SYMS, AMPS_RECC_CAPTURE_SYMS)));
-                message_port_pub(pmt::mp("records"), pmt::cons(ch, pmt::mp(&d_recs[i], sizeof(d_recs[i]))));
-            }
+            if (!push_and_publish(in + 2 * (size_t)done, (size_t)n)) return WORK_DONE;
             done += n;
         }
         consume_each(noutput_items);

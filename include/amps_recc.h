@@ -38,8 +38,10 @@
 extern "C" {
 #endif
 
-#define AMPS_RECC_ABI_VERSION 3   /* 2: amps_recc_cfg_t gained wideband_groups / wideband_group; 3: default slicer = spec D, captures track the bit
-                                     clock unless AMPS_RECC_FLAG_FIXED_TIMING, amps_recc_rccl_* / _push_wideband_bcast / _drain_gather / _debug_exact_slice added */
+#define AMPS_RECC_ABI_VERSION 4   /* 2: amps_recc_cfg_t gained wideband_groups / wideband_group; 3: default slicer = spec D, captures track the bit
+                                     clock unless AMPS_RECC_FLAG_FIXED_TIMING, amps_recc_rccl_* / _push_wideband_bcast / _drain_gather / _debug_exact_slice added;
+                                     4: amps_recc_push_wideband_dist (scatter + all-gather), amps_recc_rccl_info / _abort / _set_timeout; rccl_init checks the
+                                     group split and allocates; every collective entry is bounded and carries a status word */
 
 /* protocol constants of the reference */
 #define AMPS_RECC_TRIGGER_SYMS 74   /* lib/recc_impl.cc:76-77: 37 bits x 2 Manchester symbols   */
@@ -293,26 +295,86 @@ int amps_recc_debug_demod(amps_recc_t *h, const float *iq, size_t nsamp, int mem
                           float *demod, float *soft, uint8_t *hard);
 
 /* ---- one band over the GPUs of a node (BASELINE configs[4]: "RCCL broadcast of wideband IQ over xGMI") ----
- * One process and one handle per GPU, every handle created with cfg.wideband_groups = N, wideband_group = its rank.  Rank 0 (or
- * any one rank) calls amps_recc_rccl_unique_id and the application carries the 128 bytes to the other ranks (a file, MPI,
- * torch.distributed's store: the control plane is the application's); every rank then calls amps_recc_rccl_init -- a collective,
- * it returns when all nranks have joined -- and from then on amps_recc_push_wideband_bcast in step: the root passes its block
- * (`mem` says where it lives: a device block is used in place and stays untouched until the push after next or a drain, a host
- * block is staged by the library and free on return), the others pass NULL; the block is broadcast by RCCL
- * (ncclBroadcast) on a stream of the library's own into one of two receive buffers and pushed through the wideband seam
- * of every rank, the broadcast of push i beside the kernels of push i - 1.  Records are drained per rank as ever and carry
- * whole-band channel numbers.  RCCL is loaded at run time (librccl.so); -ENOSYS where it is absent.  nranks = 1 is valid. */
+ * One process and one handle per GPU, every handle created with cfg.wideband_groups = N, wideband_group = its rank (the reference's
+ * channels are independent -- per-instance state only, lib/recc_impl.h:31-43 -- so any split of them is exact).  Rank 0 (or any one
+ * rank) calls amps_recc_rccl_unique_id and the application carries the 128 bytes to the other ranks (a file, MPI,
+ * torch.distributed's store: the control plane is the application's); every rank then calls amps_recc_rccl_init and from then on
+ * amps_recc_push_wideband_dist (or _bcast) in step.  RCCL is loaded at run time (librccl.so, or the library the environment
+ * variable AMPS_RECC_RCCL_LIB names); -ENOSYS where it is absent.  nranks = 1 is valid.
+ *
+ * No rank is ever left waiting inside a collective (round 5):
+ *  - everything that can fail on one rank is checked or allocated BEFORE a collective and travels through it as a status word (a
+ *    16-byte all-gather in front of every push and every gather): either all ranks run the data collective or none does, and all of
+ *    them return an error -- the rank's own, or -EREMOTEIO on the ranks that were fine.  The communicator stays usable;
+ *  - every wait of the host is bounded (amps_recc_rccl_set_timeout, default 30 s, or AMPS_RECC_RCCL_TIMEOUT_MS at init): when the
+ *    other ranks do not answer the communicator is aborted and the call returns -ETIMEDOUT; from then on the collective entry
+ *    points answer -ENOTCONN (the handle itself keeps working: amps_recc_push_wideband, amps_recc_drain ...);
+ *  - a rank that has to leave (its flow graph stops, its device failed) calls amps_recc_rccl_abort: its peers then run into their
+ *    bound instead of waiting for ever.
+ *
+ * amps_recc_rccl_init is itself a collective: it returns when all nranks have joined AND compared notes.  -EINVAL on a handle built
+ * with wideband_groups = G >= 2 unless nranks == G and rank == wideband_group (it would decode part of the band and nobody the
+ * rest), or when the ranks' handles were built for different group counts; -EREMOTEIO where another rank failed; in all those
+ * cases every rank returns an error and no rank keeps a communicator.  The receive buffers (2 x the largest push) and the gather
+ * buffers are allocated here, for the capacities the ranks have in common: the smallest max_samples_per_push, the largest
+ * max_bursts.  Only a rank that cannot join at all (no id, rank outside 0 .. nranks - 1: -EINVAL at once) leaves the others
+ * waiting in RCCL's own bootstrap. */
 #define AMPS_RECC_RCCL_ID_BYTES 128
 int amps_recc_rccl_unique_id(uint8_t id[AMPS_RECC_RCCL_ID_BYTES]);
 int amps_recc_rccl_init(amps_recc_t *h, const uint8_t id[AMPS_RECC_RCCL_ID_BYTES], int nranks, int rank);
+int amps_recc_rccl_set_timeout(amps_recc_t *h, uint32_t milliseconds);
+int amps_recc_rccl_abort(amps_recc_t *h);
+/* How the step's block travels root -> everybody:
+ *   BROADCAST          one flat ncclBroadcast: every xGMI link out of the root carries the whole block B;
+ *   SCATTER_ALLGATHER  the root sends rank k its N-th of the block (ncclSend / ncclRecv in one group), then one ncclAllGather, in place:
+ *                      B/N per link and phase (~4x less time at N = 8).
+ * Both deliver the same bytes: the records do not depend on the mode. */
+#define AMPS_RECC_DIST_BROADCAST         0
+#define AMPS_RECC_DIST_SCATTER_ALLGATHER 1
+/* Every rank in step, with the same root and mode.  The root passes its block (`mem` says where it lives) and its size; the other
+ * ranks' iq / nsamp are ignored (NULL, 0): the ROOT's nsamp is what every rank pushes -- it travels in the header, so callers whose
+ * block sizes cannot be agreed beforehand (GNU Radio schedulers in different processes) need no side channel -- and comes back in
+ * *npushed (may be NULL).  The block is distributed on a stream of the library's own into one of two receive buffers and pushed
+ * through the wideband seam of every rank (amps_recc_push_wideband on the received block), the collective of push i beside the
+ * kernels of push i - 1.  Ownership of the root's block: a HOST block has been staged when the call returns and is free; a DEVICE
+ * block is read in place, behind everything enqueued on the handle's stream so far (so amps_recc_wait_event orders it behind its
+ * producer), and may be overwritten by work that is ordered behind a LATER call on this handle (amps_recc_record_event) or after a
+ * drain that covers this push.  Records are drained per rank as ever (or by amps_recc_drain_gather) and carry whole-band channel numbers.
+ * Errors: the root's -EINVAL (no block, nsamp = 0, unknown mode) / -E2BIG (beyond the smallest rank's capacity) with -EREMOTEIO on the
+ * other ranks; -EINVAL everywhere when the ranks pass different modes; -ETIMEDOUT / -ENOTCONN / -EIO: see above. */
+int amps_recc_push_wideband_dist(amps_recc_t *h, const float *iq, size_t nsamp, int mem, int root, int mode, size_t *npushed);
+/* = amps_recc_push_wideband_dist(h, iq, nsamp, mem, root, AMPS_RECC_DIST_BROADCAST, NULL) */
 int amps_recc_push_wideband_bcast(amps_recc_t *h, const float *iq, size_t nsamp, int mem, int root);
 /* The collective drain that goes with it (the burst records back to one place): every rank calls it in step; each
  * drains its own list as amps_recc_drain does (no split drain may be open) and the records of all ranks arrive at `root`, merged
  * and sorted by (channel, position) -- what one whole-band handle would have returned.  The other ranks get *nout = 0 and may pass
  * out = NULL, cap = 0.  -ENOSPC on every rank if any rank's list overflowed max_bursts (and on the root if cap is too small; what
- * fits is returned), -EIO (or the rank's own error) on every rank if any rank's drain failed: a rank never leaves the others
- * waiting in the collective.  Two small ncclAllGather calls ({count, status}, then the lists padded to the longest). */
+ * fits is returned), -EIO (or the rank's own error) on every rank if any rank's drain failed -- that rank still takes part and says
+ * so in the status word.  The header exchange ({status, count}), then one ncclAllGather of the lists padded to the longest; the wait
+ * for the handle's own kernels (which wait for the data collectives) is bounded like every other: -ETIMEDOUT. */
 int amps_recc_drain_gather(amps_recc_t *h, amps_recc_burst_t *out, size_t cap, size_t *nout, int root);
+/* What the communicator of this handle is, as RCCL itself reports it, and on which device -- enough for a record of an N-GPU run to
+ * prove N distinct devices and N ranks by itself (a handle without a communicator: nranks = 0, the device fields are filled).  collective_* : the data collectives of push_wideband_dist timed with HIP events
+ * on the library's stream (handles with kernel timing on: AMPS_RECC_FLAG_TIME_KERNELS / amps_recc_set_timing), bytes = block sizes. */
+typedef struct amps_recc_rccl_info {
+    uint32_t struct_size;
+    int32_t  alive;                 /* 1: communicator usable; 0: aborted (timeout / amps_recc_rccl_abort)            */
+    int32_t  nranks, rank;          /* as passed to amps_recc_rccl_init                                                */
+    int32_t  comm_nranks, comm_rank;/* ncclCommCount / ncclCommUserRank of the communicator (-1: not available)       */
+    int32_t  device;                /* HIP device ordinal of the handle                                                */
+    int32_t  pci_domain, pci_bus, pci_device;
+    uint8_t  device_uuid[16];       /* hipDeviceProp_t::uuid                                                           */
+    uint64_t max_samples_per_push;  /* common capacity of the ranks' handles (samples per block)                      */
+    uint32_t max_bursts_per_gather; /* longest record list of any rank                                                 */
+    uint32_t timeout_ms;
+    uint64_t collectives_timed;     /* data collectives whose events have been read                                    */
+    double   collective_ms;         /* their summed duration                                                           */
+    uint64_t collective_bytes;      /* their summed block bytes                                                        */
+    int32_t  last_mode;             /* AMPS_RECC_DIST_* of the last push, -1 before the first                          */
+    int32_t  _pad;
+    char     library[96];           /* the name librccl was loaded by                                                  */
+} amps_recc_rccl_info_t;
+int amps_recc_rccl_info(amps_recc_t *h, amps_recc_rccl_info_t *info);
 
 /* test tap of slicer spec D's bit logic, evaluated ON THE HOST by the very functions the kernels inline (no device needed):
  *   form 0: the streaming kernel's 32-sample window, oldest sample at bit 0: in = {SX, ST, SC}; out[0] = the slicer bits, exact from bit

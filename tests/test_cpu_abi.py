@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) >= 14 and set(declared) == set(capi.EXPORTS)
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.amps_recc_abi_version() == 3
+    assert L.amps_recc_abi_version() == 4
     assert L.amps_recc_burst_size() == capi.BURST_DTYPE.itemsize == oracle.BURST_DTYPE.itemsize == 728
     assert capi.BURST_DTYPE == oracle.BURST_DTYPE
     assert b"no usable HIP device" in L.amps_recc_strerror(-19)

@@ -168,3 +168,43 @@ def test_recc_wideband_block_decodes_the_band(gpu, tmp_path):
     assert out.returncode == 0, out.stderr
     got = [l for l in out.stdout.splitlines() if l.startswith("MSG ")]
     assert sorted(got) == sorted(want) and [l for l in got if l.startswith("MSG channel")] != []
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_recc_wideband_blocks_share_one_band_over_four_processes(gpu, tmp_path, mode):
+    """gr::amps::recc_wideband::set_rccl (BASELINE configs[4] on the flow-graph side): four processes, one block each, channel groups 0..3;
+    rank 0 owns the capture and the library distributes it (mode 0: broadcast, 1: scatter + all-gather).  The schedulers of separate flow
+    graphs do not agree on item counts: the ranks here are fed in DIFFERENT chunk sizes, the non-root ranks' items are
+    ignored, and the ranks stay in step by stream position.  The union of what the four processes print is what ONE whole-band block
+    prints.  (Transport between the processes: the loop-back stand-in of tests/loopccl -- RCCL refuses four ranks on one GPU.)"""
+    import loopccl
+    from gr_amps_amd import synth_wideband as sw
+    n = int(0.26 * sw.FS_WIDE) // 512 * 512
+    planted = [(96 + c, off) for c, off in ((7, 150000), (16, 400000), (40, 90000), (63, 230000), (500, 60000), (831, 300000))]   # all four groups
+    x, truth = sw.make_wideband(n, planted, seed=43)
+    p = tmp_path / "band.fc32"
+    x.tofile(p)
+    _, exe = build_host()
+    one = subprocess.run([exe, "wide", str(p), "777777"], capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stderr
+    want = [l for l in one.stdout.splitlines() if l.startswith("MSG ")]
+    assert sum(1 for l in want if l.startswith("MSG channel")) == len(planted)
+    env = dict(os.environ, AMPS_RECC_RCCL_LIB=loopccl.build(), LOOPCCL_DIR=str(tmp_path))
+    chunks = ["600000", "77777", "2000001", "333333"]            # rank 0's cut of the stream, and three others that share nothing with it
+    procs = [subprocess.Popen([exe, "widerank", str(p), chunks[r], str(tmp_path / "id.bin"), "4", str(r), str(mode)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(4)]
+    got = []
+    for r, q in enumerate(procs):
+        try:
+            o, e = q.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for k in procs:
+                k.kill()
+            raise AssertionError("rank %d hung" % r)
+        assert q.returncode == 0, (r, e[-2000:])
+        lines = [l for l in o.splitlines() if l.startswith("MSG ")]
+        for l in lines:
+            if l.startswith("MSG channel"):                       # a rank publishes its own group only: (bin mod 64) in its window of 16
+                assert ((96 + int(l.split()[2])) % 64) // 16 == r
+        got += lines
+    assert sorted(got) == sorted(want)

@@ -91,3 +91,26 @@ def test_tolerant_sync_on_the_wideband_seam(gpu):
 def test_tolerance_out_of_range_is_rejected(gpu):
     with pytest.raises(capi.AmpsError):
         capi.Recc(n_channels=1, sps=10, max_samples=4096, max_bursts=4, sync_tolerance=9)
+
+
+@pytest.mark.parametrize("sps,lead_syms", [(10, 0), (10, 3), (10, 6), (4, 5), (3, 4)])
+def test_tolerant_trigger_that_begins_in_front_of_the_stream(gpu, sps, lead_syms):
+    """with sync_tolerance > 0 a trigger may begin BEFORE the first sample (its first symbols are the tolerated wrong
+    ones); block 0 of the capture's timing tracking then looks in front of the stream, where the CPU model reads 1 (gbit()).  The
+    device used to read stream bit 0 unshifted there.  The stream here starts `lead_syms` symbols INTO the trigger of its first burst."""
+    rng = np.random.default_rng(77 + sps + lead_syms)
+    kind, min10, esn, dialed, words = synth.random_message(rng)
+    bits = synth.burst_bits(words, dcc=2, rng=rng)
+    n = (len(bits) * 2 + 400) * sps
+    iq = synth.fsk_modulate(n + 200 * sps, [(200 * sps, bits)], sps=sps, fs=20e3 * sps, snr_db=30.0, rng=rng)
+    # the trigger's first symbol = burst symbol 8 (burst bits [4, 41)): cut the stream `lead_syms` symbols behind it
+    cut = 200 * sps + (8 + lead_syms) * sps
+    x = np.ascontiguousarray(iq[cut:cut + (n // 64) * 64])
+    for k in (0, 8):
+        with capi.Recc(n_channels=1, sps=sps, max_samples=x.size, max_bursts=8, sync_tolerance=k) as r:
+            r.push_iq(x[None, :])
+            got = r.drain()
+        want = oracle.fused_push_all(x[None, :], sps=sps, tolerance=k)
+        assert got.tobytes() == want.tobytes(), (k, len(got), len(want))
+        if k == 8 and lead_syms in (3, 4, 5, 6):                 # found although its first symbols were never received, and decoded
+            assert len(got) == 1 and got[0]["min"].decode() == min10
