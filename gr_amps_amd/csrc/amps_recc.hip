@@ -38,6 +38,8 @@ using namespace amps;
         }                                                                               \
     } while (0)
 
+constexpr size_t LIST_WORDS = 4;   // a record list's device-side words: {slot allocator, status, published count (recc_resolve.hip.h: publish_header), pad}
+
 enum { T_FRONT = 0, T_RESOLVE, T_DECODE, T_CARRY, T_SYMBOLS, T_CHANNELIZER, T_XLATE, T_COUNT };
 
 struct TimedSpan { hipEvent_t a, b; int tag; uint64_t samples; };
@@ -67,7 +69,7 @@ struct amps_recc {
     uint64_t *det = nullptr;
     uint32_t *detcount = nullptr;
     uint64_t *next_allowed = nullptr, *pending = nullptr;
-    uint32_t *done_blocks = nullptr;              // resolve workgroups of the launch in flight that have finished
+    unsigned long long *done_blocks = nullptr;    // {resolve workgroups of the launch in flight that have finished, record slots they reserved}
     uint64_t *capq = nullptr;                     // queue form of the capture (few channels: resolve_uses_queue)
     uint32_t *capq_count = nullptr;
     amps_recc_burst_t *records = nullptr;
@@ -220,11 +222,11 @@ int reset_state(amps_recc *h)
         HIP_TRY(hipMemsetAsync(h->detcount, 0, sizeof(uint32_t) * (size_t)h->C * h->max_chunks, s));
         HIP_TRY(hipMemsetAsync(h->next_allowed, 0, sizeof(uint64_t) * h->C, s));
         HIP_TRY(hipMemsetAsync(h->pending, 0xff, sizeof(uint64_t) * h->C, s));
-        HIP_TRY(hipMemsetAsync(h->done_blocks, 0, (1 + DONE_GROUPS) * sizeof(uint32_t), s));
+        HIP_TRY(hipMemsetAsync(h->done_blocks, 0, (1 + DONE_GROUPS) * sizeof(unsigned long long), s));
         if (h->capq_count) HIP_TRY(hipMemsetAsync(h->capq_count, 0, sizeof(uint32_t), s));
     }
     for (int b = 0; b < 2; b++) {
-        HIP_TRY(hipMemsetAsync(h->nrecords_buf[b], 0, 2 * sizeof(uint32_t), s));
+        HIP_TRY(hipMemsetAsync(h->nrecords_buf[b], 0, LIST_WORDS * sizeof(uint32_t), s));
         h->list_clean[b] = true;
     }
     std::memset(h->hdr_host, 0, 2 * HDR_STRIDE * sizeof(uint32_t));
@@ -507,6 +509,11 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
     if (dev >= ndev) return -ENODEV;
     if (hipSetDevice(dev) != hipSuccess) return -ENODEV;
 
+    // AMPS_RECC_TRACE_CREATE=1: the steps of this function to stderr (which HIP call a creation hangs or crawls in when many
+    // processes share one device -- the 8-rank rehearsals of tests/test_gpu_bench_ranks.py)
+    const bool trace = std::getenv("AMPS_RECC_TRACE_CREATE") != nullptr;
+    auto step = [&](const char *what) { if (trace) { std::fprintf(stderr, "amps_recc_create[%d]: %s\n", (int)getpid(), what); std::fflush(stderr); } };
+    step("device set");
     amps_recc *h = new (std::nothrow) amps_recc();
     if (!h) return -ENOMEM;
     h->cfg = *cfg;
@@ -532,9 +539,10 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
     }
     int rc = 0;
     const size_t C = h->C;
+    step("stream created");
     // results + symbol seam (always present)
     for (int b = 0; b < 2; b++) {   // {nrecords, status} of a list are adjacent: one 8-byte copy / memset serves both
-        rc |= dev_alloc(&h->nrecords_buf[b], 2);
+        rc |= dev_alloc(&h->nrecords_buf[b], LIST_WORDS);
         h->status_buf[b] = h->nrecords_buf[b] ? h->nrecords_buf[b] + 1 : nullptr;
     }
     rc |= dev_alloc(&h->symbuf, C * AMPS_RECC_SYMBUF);
@@ -544,6 +552,7 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
     rc |= dev_alloc(&h->bursts_dev, (size_t)cfg->max_bursts * AMPS_RECC_CAPTURE_SYMS);
     rc |= dev_alloc(&h->burst_chan_dev, cfg->max_bursts);
     rc |= dev_alloc(&h->nbursts_dev, 1);
+    step("symbol seam buffers allocated");
     // result records live in mapped, pinned host memory (zero copy: 728 B per burst over PCIe while the
     // kernels run); h->records is the device-side view of the same allocation
     for (int b = 0; b < 2; b++)
@@ -557,6 +566,7 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
         hipHostGetDevicePointer((void **)&h->hdr_dev, h->hdr_host, 0) != hipSuccess) rc |= -ENOMEM;
     if (hipEventCreateWithFlags(&h->drain_event, hipEventDisableTiming) != hipSuccess) rc |= -ENOMEM;
     if (!rc) select_record_list(h, 0);
+    step("pinned record lists mapped");
     // IQ seam
     if (!rc && cfg->max_samples_per_push) {
         const uint64_t maxs = cfg->max_samples_per_push;
@@ -593,8 +603,11 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
         rc |= dev_alloc(&h->done_blocks, 1 + DONE_GROUPS);
         if (resolve_uses_queue((uint32_t)C)) { rc |= dev_alloc(&h->capq, cfg->max_bursts); rc |= dev_alloc(&h->capq_count, 1); }
     }
+    step("IQ seam buffers allocated");
     if (!rc && cfg->wideband_channels) rc = channelizer_create(h->chz, *cfg, h->stream);
+    step("channelizer created");
     if (!rc) rc = reset_state(h);
+    step("state reset");
     if (rc) { amps_recc_destroy(h); return rc; }
     *out = h;
     return 0;
@@ -1101,7 +1114,7 @@ int amps_recc_drain_begin(amps_recc_t *h)
     h->open_untouched = true;
     select_record_list(h, b ^ 1);           // later pushes append to the other list
     if (!h->list_clean[b ^ 1]) {            // drained twice with no push in between: nobody has cleared it yet
-        HIP_TRY(hipMemsetAsync(h->nrecords_buf[b ^ 1], 0, 2 * sizeof(uint32_t), s));
+        HIP_TRY(hipMemsetAsync(h->nrecords_buf[b ^ 1], 0, LIST_WORDS * sizeof(uint32_t), s));
         h->list_clean[b ^ 1] = true;
     }
     return 0;

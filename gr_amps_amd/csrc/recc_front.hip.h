@@ -101,7 +101,7 @@ struct FrontArgs {
     uint32_t tol;            // TOL kernels: accepted mismatching trigger symbols (cfg.sync_tolerance)
     uint32_t force_ones;     // spec B: rel samples [0, force_ones) have no partner yet (stream start): g = 1
     uint32_t *zero1;         // housekeeping done by thread 0 of the launch instead of separate memsets on the stream: one dword to
-    uint32_t *zero2;         // clear (the capture queue count) and an optional pair (the idle record list's {count, status})
+    uint32_t *zero2;         // clear (the capture queue count) and an optional triple (the idle record list's {count, status, published count})
     float2   *carry_out;     // optional: the NEXT push's carry, [C][CARRY_CAP], written by this launch (a slice per wave) instead of by
     uint32_t carry_n;        // recc_carry_kernel behind it: carry_out[c][k] = sample P - HALO + k, k < carry_n = HALO + leftover
 };
@@ -109,7 +109,7 @@ __device__ __forceinline__ void front_housekeeping(const FrontArgs &a)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (a.zero1) *a.zero1 = 0u;
-        if (a.zero2) { a.zero2[0] = 0u; a.zero2[1] = 0u; }
+        if (a.zero2) { a.zero2[0] = 0u; a.zero2[1] = 0u; a.zero2[2] = 0u; }
     }
 }
 

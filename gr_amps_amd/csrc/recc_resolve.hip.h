@@ -39,7 +39,7 @@ struct ResolveArgs {
     uint32_t majority;         // decode mode (AMPS_RECC_FLAG_MAJORITY)
     uint32_t track;            // timing tracking inside a capture (off: AMPS_RECC_FLAG_FIXED_TIMING)
     uint8_t *burst_syms;       // optional [rec_cap][3374]: the captured symbols of record `slot` (AMPS_RECC_FLAG_KEEP_BURSTS)
-    uint32_t *done_blocks;     // [1 + DONE_GROUPS] workgroups of this launch that have finished (the last one publishes the header; see DONE_GROUPS)
+    unsigned long long *done_blocks;   // [1 + DONE_GROUPS] {workgroups of this launch that have finished, record slots they reserved} (the last one publishes the header; see DONE_GROUPS)
     uint32_t *hdr_host;        // mapped pinned {nrecords, status} of the record list: what a drain reads, no copy on the stream
     // queue form (few channels, see resolve_uses_queue): accepted captures go to a queue and recc_capture_kernel decodes them
     uint64_t *capq;            // [capq_cap] (channel << CAPQ_POS_BITS | n_c), or null: decode in this kernel
@@ -123,22 +123,35 @@ __device__ __forceinline__ void capture_store_wave(const ResolveArgs &a, uint64_
 // DONE_GROUPS group counters (channel mod DONE_GROUPS) and only the last of a group steps the top counter; and a workgroup reserves
 // the record slots of a whole batch of captures with one atomic, issued behind the first ring loads and consumed after the decode.
 constexpr uint32_t DONE_GROUPS = 32;       // done_blocks[0] = top counter, [1 + g] = group g
-// A workgroup counts itself done.  The last one reads `nrecords` and publishes it to the host header; what that value must contain is
-// every workgroup's slot reservation (a device-scope atomic on nrecords issued before its done-count).  Relaxed atomics leave that to
-// where the hardware performs device-scope atomics (in order at the memory side of the L2s; cross-checked by
-// AMPS_RECC_CHECK_HEADER); release on the counting side + acquire on the reading side make it a guarantee of the memory model: the
-// reservation happens-before the last workgroup's read (ADVICE r03 / VERDICT r04 item 6).  The release waits for the counting WAVE's
-// earlier stores only (s_waitcnt + L2 write-back, no device-wide fence).  -DAMPS_RESOLVE_DONE_ACQREL=0 restores the relaxed form (A/B).
-#ifndef AMPS_RESOLVE_DONE_ACQREL
-#define AMPS_RESOLVE_DONE_ACQREL 1
+// A workgroup counts itself done, and in the SAME atomic says how many record slots it reserved in this launch: the counters are
+// 64 bits, {workgroups done (low word), slots reserved (high word)}.  The workgroup that finishes last therefore knows the launch's
+// record count from the value its own read-modify-write returns -- atomicity on ONE address, no ordering between two addresses
+// needed -- adds it to the list's published count (a plain word only ever touched by that one thread of a launch, and launches are
+// stream-ordered) and writes the header.  Rounds 3-4 had the last workgroup read `nrecords` after its done-count with relaxed
+// atomics, which holds on this hardware (device-scope atomics are performed in issue order at the memory side of the L2s, DESIGN.md
+// 4.4) but is not a guarantee of the memory model; release / acquire on the old counters would have
+// been: measured +15 us per launch (resolve + capture + decode 0.0317 -> 0.0468 ms at 416 bursts, profiles/r05/done_counters.txt),
+// because a release waits for the counting wave's 728-byte record stores to cross PCIe.  The packed count needs no ordering at all, so
+// the read-modify-writes stay RELAXED (AMPS_RESOLVE_DONE_ORDER: an acquire on them measured +2.5 us).  The status word is read
+// relaxed as well: the one bit that can be set inside the publishing launch -- 4, record list overflow -- is implied by the count the
+// host compares with max_bursts anyway (drain_end_impl), bit 2 (capture queue overflow) is set by the kernel in FRONT of the one that
+// publishes in the queue form, bit 1 by the search kernel in front of both: kernel boundaries order those.
+// AMPS_RECC_CHECK_HEADER (on in the test suite) still cross-checks the header against a copy of the device counters.
+#ifndef AMPS_RESOLVE_DONE_ORDER
+#define AMPS_RESOLVE_DONE_ORDER __ATOMIC_RELAXED
 #endif
-__device__ __forceinline__ uint32_t count_done(uint32_t *p)
+__device__ __forceinline__ unsigned long long count_done(unsigned long long *p, uint32_t done, unsigned long long reserved)
 {
-#if AMPS_RESOLVE_DONE_ACQREL
-    return __hip_atomic_fetch_add(p, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-#else
-    return atomicAdd(p, 1u);
-#endif
+    return __hip_atomic_fetch_add(p, (reserved << 32) | done, AMPS_RESOLVE_DONE_ORDER, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the last workgroup of the launch: the list's running {count, status} to the device-side mirror and the host header
+__device__ __forceinline__ void publish_header(uint32_t *nrecords /* {slot allocator, status, published count} */, uint32_t *status,
+                                               volatile uint32_t *hdr_host, unsigned long long launch_total)
+{
+    const uint32_t total = nrecords[2] + (uint32_t)launch_total;
+    nrecords[2] = total;
+    hdr_host[0] = total;
+    hdr_host[1] = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 constexpr int RESOLVE_THREADS = 256;       // many channels, few segments each
@@ -173,9 +186,11 @@ __global__ __launch_bounds__(THREADS, 4) void recc_resolve_kernel(ResolveArgs a)
 
     // accepted captures are collected in LDS; the first CAP_WAVES waves then capture and decode them, one each per round.  The
     // slots of the whole batch are reserved by the last wave with one atomic whose round trip hides behind the first decode.
+    uint32_t reserved = 0;                                            // record slots this workgroup has reserved in this launch (uniform)
     auto flush = [&]() {                                              // all threads
         __syncthreads();
         const uint32_t m = s_nacc;
+        if (!a.capq) reserved += m;
         if (m && a.capq) {                                            // queue form: one atomicAdd per batch
             if (tid == 0) s_base = atomicAdd(a.capq_count, m);
             __syncthreads();
@@ -307,12 +322,14 @@ __global__ __launch_bounds__(THREADS, 4) void recc_resolve_kernel(ResolveArgs a)
         const uint32_t ng = gridDim.x < DONE_GROUPS ? gridDim.x : DONE_GROUPS;
         const uint32_t g = blockIdx.x % DONE_GROUPS;
         const uint32_t gsize = (gridDim.x - g + DONE_GROUPS - 1) / DONE_GROUPS;
-        if (count_done(a.done_blocks + 1 + g) == gsize - 1) {
-            atomicExch(a.done_blocks + 1 + g, 0u);
-            if (count_done(a.done_blocks) == ng - 1) {
-                a.hdr_host[0] = atomicAdd(a.nrecords, 0u);
-                a.hdr_host[1] = atomicOr(a.status, 0u);
-                atomicExch(a.done_blocks, 0u);
+        const unsigned long long gv = count_done(a.done_blocks + 1 + g, 1u, reserved);
+        if ((uint32_t)gv == gsize - 1) {
+            const unsigned long long gtot = (gv >> 32) + reserved;    // the group's reservations: everybody's before mine, and mine
+            atomicExch(a.done_blocks + 1 + g, 0ull);
+            const unsigned long long tv = count_done(a.done_blocks, 1u, gtot);
+            if ((uint32_t)tv == ng - 1) {
+                publish_header(a.nrecords, a.status, a.hdr_host, (tv >> 32) + gtot);
+                atomicExch(a.done_blocks, 0ull);
             }
         }
         RTL(7);
@@ -329,7 +346,9 @@ __global__ __launch_bounds__(64) void recc_capture_kernel(ResolveArgs a)
     const int lane = threadIdx.x;
     uint32_t ncap = *a.capq_count;
     if (ncap > a.capq_cap) ncap = a.capq_cap;
+    uint32_t reserved = 0;
     for (uint32_t q = blockIdx.x; q < ncap; q += gridDim.x) {
+        reserved++;
         const uint64_t e = a.capq[q];
         const uint32_t c = (uint32_t)(e >> CAPQ_POS_BITS);
         const uint64_t nc = e & ((1ull << CAPQ_POS_BITS) - 1);
@@ -346,11 +365,10 @@ __global__ __launch_bounds__(64) void recc_capture_kernel(ResolveArgs a)
     // take part
     const uint32_t nb = ncap < gridDim.x ? (ncap ? ncap : 1u) : gridDim.x;
     if (lane == 0 && blockIdx.x < nb) {
-        const uint32_t t = count_done(a.done_blocks);
-        if (t == nb - 1) {
-            a.hdr_host[0] = atomicAdd(a.nrecords, 0u);
-            a.hdr_host[1] = atomicOr(a.status, 0u);
-            atomicExch(a.done_blocks, 0u);
+        const unsigned long long t = count_done(a.done_blocks, 1u, reserved);
+        if ((uint32_t)t == nb - 1) {
+            publish_header(a.nrecords, a.status, a.hdr_host, (t >> 32) + reserved);
+            atomicExch(a.done_blocks, 0ull);
         }
     }
 }

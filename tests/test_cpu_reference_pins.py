@@ -1,0 +1,100 @@
+"""Holds the oracle (oracle/ref_chain.c) to REFERENCE-PRODUCED vectors -- tests/golden/reference_pins.npz, which only a machine with
+GNU Radio 3.7 + IT++ and the built reference can make (scripts/pin_with_reference.sh -> scripts/pin/run_reference.py, from the
+committed inputs tests/golden/pin_inputs.npz).  This image has neither, so today the comparison is SKIPPED and parity stays
+"partial" (DESIGN.md section 2); the day the file is committed, this test is what pins rows R2, R3-R8 (+ replies), G1-G4.
+
+What runs today: the oracle's side of the comparison on the committed inputs (so the recipe's own plumbing cannot rot), held to the
+stream outcomes SURVEY.md 8(a) recorded from the reference's compiled code (Q1: strict '>', Q4: the first-fill wrap)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+INPUTS = os.path.join(GOLDEN, "pin_inputs.npz")
+REFERENCE = os.path.join(GOLDEN, "reference_pins.npz")
+
+
+def _bits(a):
+    return "".join(str(int(b)) for b in a)
+
+
+def _reply_lines(rec):
+    r = oracle.reply_words(rec)
+    lines = []
+    if r.has_focc:
+        lines.append("MSG focc_words stream=%d n=%d w1=%s w2=%s" % (r.focc_stream, r.focc_nwords, _bits(r.focc_word1), _bits(r.focc_word2)))
+    if r.has_fvc:
+        lines.append("MSG fvc_words n=%d w1=%s repeat=%d" % (r.fvc_count, _bits(r.fvc_word1), r.fvc_repeat))
+    if r.has_mutes:
+        lines.append("MSG fvc_mute %d" % r.fvc_mute)
+        lines.append("MSG audio_mute %d" % r.audio_mute)
+    if r.has_command:
+        lines.append("MSG command_out " + r.command.decode())
+    return lines
+
+
+def oracle_side(inp):
+    """what scripts/pin/run_reference.py computes with the reference, computed with the oracle: same keys, 'ref_' -> 'orc_'"""
+    out = {}
+    for key in [k for k in inp.files if k.startswith("sym_")]:
+        pubs = oracle.Recc().run(inp[key].astype(np.uint8), 4096)
+        out["orc_" + key + "_bursts"] = np.stack([b for _, b in pubs]) if pubs else np.zeros((0, 3374), np.uint8)
+    recs = oracle.decode_bursts(inp["bursts"])
+    out["orc_burst_lines"] = [_reply_lines(r) for r in recs]
+    taps = oracle.firdes_low_pass(3.0, 400e3, 10e3, 4.5e3)
+    out["orc_g1_taps"] = taps
+    out["orc_g1_out"] = oracle.freq_xlating_fir(inp["iq400"], taps, 160e3, 400e3, 2)
+    out["orc_g2_out"] = oracle.quadrature_demod(inp["iq200"])
+    _, syms = oracle.chain_iq200(inp["iq200"], want_symbols=True)
+    out["orc_g4_out"] = syms
+    return out
+
+
+@pytest.fixture(scope="module")
+def sides():
+    inp = np.load(INPUTS)
+    return inp, oracle_side(inp)
+
+
+def test_the_recipes_inputs_and_the_oracles_side_of_it(sides):
+    inp, orc = sides
+    # the stream outcomes the survey recorded from the reference's compiled code hold on these inputs
+    assert len(orc["orc_sym_spaced_bursts"]) == 6
+    assert len(orc["orc_sym_q1_short_tail_bursts"]) == 0 and len(orc["orc_sym_q1_one_more_bursts"]) == 1
+    assert len(orc["orc_sym_q4_lost_bursts"]) == 0 and len(orc["orc_sym_q4_kept_bursts"]) == 1
+    assert len(orc["orc_burst_lines"]) == len(inp["bursts"]) and sum(1 for l in orc["orc_burst_lines"] if l) >= 18
+    assert orc["orc_g1_taps"].size == 299 and abs(float(orc["orc_g1_taps"].sum()) - 3.0) < 1e-4
+    assert orc["orc_g1_out"].size == inp["iq400"].size // 2 and orc["orc_g2_out"].size == inp["iq200"].size
+    assert 6000 < orc["orc_g4_out"].size < 7000 and set(np.unique(orc["orc_g4_out"])) <= {0, 1}
+
+
+@pytest.mark.skipif(not os.path.exists(REFERENCE), reason="tests/golden/reference_pins.npz does not exist: the reference cannot be built in this image "
+                    "(scripts/pin_with_reference.sh is the recipe for a machine with GNU Radio 3.7 + IT++) -- parity stays 'partial'")
+def test_oracle_equals_the_reference_on_the_pin_inputs(sides):
+    inp, orc = sides
+    ref = np.load(REFERENCE)
+    # R1 / R2: the very blobs, in order
+    for key in [k for k in inp.files if k.startswith("sym_")]:
+        assert ref["ref_" + key + "_bursts"].tobytes() == orc["orc_" + key + "_bursts"].tobytes(), key
+    # R3 .. R8 + reply generation: every message recc_decode publishes for every burst
+    owner = ref["ref_burst_line_owner"]
+    lines = [str(l) for l in ref["ref_burst_lines"]]
+    for i, want in enumerate(orc["orc_burst_lines"]):
+        got = [lines[j] for j in range(len(owner)) if owner[j] == i and lines[j]]
+        assert sorted(got) == sorted(want), (i, got, want)
+    # G1: firdes.low_pass taps and the translating filter's output (float: the rotator is renormalised, the dot product's order is VOLK's)
+    assert ref["ref_g1_taps"].size == orc["orc_g1_taps"].size
+    assert np.allclose(ref["ref_g1_taps"], orc["orc_g1_taps"], rtol=0, atol=2e-7)
+    n = min(ref["ref_g1_out"].size, orc["orc_g1_out"].size)
+    assert n >= inp["iq400"].size // 2 - 4
+    assert np.abs(ref["ref_g1_out"][:n] - orc["orc_g1_out"][:n]).max() < 5e-5 * max(1.0, float(np.abs(ref["ref_g1_out"]).max()))
+    # G2: quadrature_demod_cf with fast_atan2f -- the literal table, so nearly exact (history: the first output uses a zero sample)
+    n = min(ref["ref_g2_out"].size, orc["orc_g2_out"].size)
+    assert np.abs(ref["ref_g2_out"][1:n] - orc["orc_g2_out"][1:n]).max() < 2e-6
+    # G3 + G4: the symbols the Mueller & Mueller loop hands amps.recc -- byte for byte (the loop's arithmetic is 'read side by side only' today)
+    m = min(ref["ref_g4_out"].size, orc["orc_g4_out"].size)
+    assert abs(ref["ref_g4_out"].size - orc["orc_g4_out"].size) <= 2
+    assert np.array_equal(ref["ref_g4_out"][:m], orc["orc_g4_out"][:m])

@@ -29,7 +29,7 @@ def _run(extra, n=2, samples=1 << 24):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1",
            "--samples", str(samples), "--prewarm-ms", "20", "--no-cpu-baseline", "--no-power-sample"] + extra
-    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]                    # rank 0 prints ONE line
@@ -93,7 +93,7 @@ def test_four_and_eight_ranks_under_the_launcher(gpu, n):
     assert d["secondary_abi"]["collective"]["op"] == "scatter_allgather" and "libamps_recc" in d["secondary_abi"]["collective"]["issued_by"]
 
 
-@pytest.mark.parametrize("n,mode", [(4, "broadcast"), (8, "scatter_allgather_abi"), (2, "broadcast_abi")])
+@pytest.mark.parametrize("n,mode", [(8, "scatter_allgather_abi"), (2, "broadcast_abi")])
 def test_one_band_modes_as_the_headline(gpu, n, mode):
     ns = 1 << 23
     d = _run(["--dist", mode], n, ns)

@@ -49,14 +49,15 @@ def stream(gpu, tmp_path_factory):
 def _run(stream, tmp_path, nranks, scenario, mode="broadcast", root=0, env_extra=None, expect_fail=()):
     for f in ("x.npy", "n.npy"):
         os.symlink(stream["dir"] / f, tmp_path / f)
-    env = dict(os.environ, AMPS_RECC_RCCL_LIB=stream["lib"], LOOPCCL_DIR=str(tmp_path), LOOPCCL_TIMEOUT_MS="60000", **(env_extra or {}))
+    env = dict(os.environ, AMPS_RECC_RCCL_LIB=stream["lib"], LOOPCCL_DIR=str(tmp_path), LOOPCCL_TIMEOUT_MS="60000")
+    env.update(env_extra or {})
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rank_worker.py"), "--rank", str(r), "--nranks", str(nranks), "--dir", str(tmp_path),
                                "--scenario", scenario, "--mode", mode, "--root", str(root)], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(nranks)]
     outs = []
     for r, p in enumerate(procs):
         try:
-            o, _ = p.communicate(timeout=300)
+            o, _ = p.communicate(timeout=120)
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
