@@ -340,6 +340,22 @@ def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, w
     dist_mode = dist_mode or a.dist
     one_band = wide and dist is not None and dist_mode != "bands"
     planted = None
+    # test knob (tests/test_gpu_bench_ranks.py): N ranks on ONE device.  Their batch syntheses -- thousands of small torch kernels each --
+    # then run one rank after the other: eight processes with deep queues on one GPU are time-sliced per PROCESS by the kernel driver
+    # and did not finish in seven minutes (all eight sat in the first synchronising HIP call of amps_recc_create behind their own
+    # queues; AMPS_RECC_TRACE_CREATE).  On a node every rank has its own device and nothing is serialised.
+    stagger = dist is not None and world > 1 and os.environ.get("AMPS_BENCH_SHARE_GPU") == "1"
+
+    def build_in_turn(fn):
+        if not stagger:
+            return fn()
+        out = None
+        for turn in range(world):
+            if turn == rank:
+                out = fn()
+                torch.cuda.synchronize()
+            dist.barrier()
+        return out
     if wide:
         # config 3: the whole 832-channel band from one 30.72 Msps stream through the polyphase channelizer
         sps, C, first_bin = 3, 832, 96
@@ -353,7 +369,7 @@ def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, w
             # in its window, and its filter-bank kernel skips pass 3 and the slicer for everybody else's bins
             mine = [c for c in range(832) if (((96 + c) % 1024) % 64) // (64 // groups) == group]
             wb.update(groups=groups, group=group)
-            batch, planted = make_wideband_batch(torch, dev, NW, 96, 832, 2, seed=1, build=(rank == 0))   # (only rank 0's copy is ever read)
+            batch, planted = build_in_turn(lambda: make_wideband_batch(torch, dev, NW, 96, 832, 2, seed=1, build=(rank == 0)))   # (only rank 0's copy is ever read)
             planted = {c: m for c, m in planted.items() if c in set(mine)}
             C = len(mine)
         elif one_band:                                    # world sizes without a group split: contiguous channel ranges, whole filter bank per rank
@@ -361,10 +377,10 @@ def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, w
             first_bin = 96 + rank * C
             wb["first_channel"] = first_bin
             n_band = C
-            batch, planted = make_wideband_batch(torch, dev, NW, 96, 832, 2, seed=1, build=(rank == 0))
+            batch, planted = build_in_turn(lambda: make_wideband_batch(torch, dev, NW, 96, 832, 2, seed=1, build=(rank == 0)))
             planted = {c - rank * C: m for c, m in planted.items() if rank * C <= c < (rank + 1) * C}
         else:
-            batch, planted = make_wideband_batch(torch, dev, NW, first_bin, C, 2, seed=rank + 1)
+            batch, planted = build_in_turn(lambda: make_wideband_batch(torch, dev, NW, first_bin, C, 2, seed=rank + 1))
         abi_mode = {"broadcast_abi": "broadcast", "scatter_allgather_abi": "scatter_allgather"}.get(dist_mode) if one_band else None
         if one_band and not abi_mode:
             recv = [torch.empty_like(batch), torch.empty_like(batch)]

@@ -23,13 +23,13 @@ def _port():
         return s.getsockname()[1]
 
 
-def _run(extra, n=2, samples=1 << 24):
+def _run(extra, n=2, samples=1 << 24, timeout=300):
     import loopccl
     env = dict(os.environ, AMPS_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", AMPS_RECC_RCCL_LIB=loopccl.build(), OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1",
            "--samples", str(samples), "--prewarm-ms", "20", "--no-cpu-baseline", "--no-power-sample"] + extra
-    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]                    # rank 0 prints ONE line
