@@ -534,12 +534,24 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? AMPS_FRONT_D2_BL
         if (k + DEPTH < K) load_tile(nxt[DEPTH - 1], t0 + DEPTH * TILE);
         f2 *const xs = (f2 *)s_d;
         {
+#ifdef AMPS_FRONT_LDS_LINEAR_STORES_EXPERIMENT
+            // TIMING EXPERIMENT ONLY (profiles/r05/front_lds_conflicts.txt): the stores go to an unpadded, perfectly linear layout -- no
+            // bank conflict at all, and WRONG results (the reads keep the padded layout) -- to see what the real layout's 17 % of
+            // conflict cycles cost the kernel
+            f2 *const xw = xs + 2 * lane;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                xw[XHIST + 128 * q] = (f2){ cur[q].x, cur[q].y };
+                xw[XHIST + 128 * q + 1] = (f2){ cur[q].z, cur[q].w };
+            }
+#else
             f2 *const xw = xs + 2 * lane + (lane >> 2);              // xidx(XHIST + 128 q + 2 lane + e) = const + this
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 xw[xidx(XHIST + 128 * q)] = (f2){ cur[q].x, cur[q].y };
                 xw[xidx(XHIST + 128 * q) + 1] = (f2){ cur[q].z, cur[q].w };
             }
+#endif
         }
         __builtin_amdgcn_wave_barrier();
         {
