@@ -259,6 +259,7 @@ __device__ __forceinline__ void chz_p3(cf2 *A, const cf2 (&tw)[NT], int lane)
 struct ChzIn {
     const float2 *block, *carry;
     int64_t hist, lead, carry_len, nsamp;
+    uint32_t f_last;         // last launch-relative frame whose CHZ_D samples lie wholly inside the new block (FAST prefetch clamp)
     __device__ __forceinline__ cf2 generic(int64_t v) const
     {
         const int64_t ci = v + hist;
@@ -382,9 +383,13 @@ __device__ __forceinline__ void chz_load1_ring(cf2 (&ring)[4][P + 4], const ChzI
         const uint32_t voff = (uint32_t)t * (uint32_t)sizeof(float2);
         // wave-uniform; clamped to the last whole frame of the block: the prefetch runs two half-steps ahead of the fold and so
         // up to eight frames past the end of the data -- those loads fetch valid memory nobody folds
-        int64_t off = (F + G) * CHZ_D - in.lead;
-        if (off > in.nsamp - CHZ_D) off = in.nsamp - CHZ_D;
-        const float2 *q = in.block + off;
+        // (F + G >= 0 on this path: the half-batch in work lies inside the block and the prefetch only runs ahead of it.  The clamp is
+        // done on the FRAME index, in 32 bits, so that it stays on the scalar unit: gfx950 has no 64-bit scalar ordered compare, and
+        // `off > nsamp - D` on 64-bit sample offsets became a v_cmp_lt_i64 per load pair, four per half-step, in the role whose
+        // instructions cost the step most.  f_last = the last frame that lies wholly inside the block.)
+        uint32_t f = (uint32_t)(F + G);
+        f = f < in.f_last ? f : in.f_last;
+        const float2 *q = in.block + ((int64_t)f * CHZ_D - in.lead);
         // "+v": the destination is TIED to the register that holds the slot's dead value, so the new value is born in the ring's own
         // register -- with "=v" the compiler is free to load into a scratch pair and copy it into place at the next control-flow
         // join, i.e. to READ a register whose load is still in flight (it did: tests/test_cpu_inflight_loads.py scans the
@@ -534,6 +539,27 @@ template <int SL> struct ChzSlicePair {
             for (int g = 0; g < 4; g++) { if (g & 1) step<1>(yr[g], yi[g]); else step<0>(yr[g], yi[g]); }
         }
     }
+    // Spec D with the three frames of history handed in instead of kept: hr[0] / hi[0] = the bins one frame before yr[0], hr[1] two,
+    // hr[2] three.  Nothing is copied at the end -- the caller's four frames ARE the next step's history (ChzSlicer::half: two
+    // buffers used alternately, the parity a compile-time constant).  Round 4 kept (pr, pi, h2, h3) as members: six v_mov_b64 per
+    // channel pair and time step across the loop's back edge, 12 of the kernel's 528 VALU instructions per frame.
+    __device__ __forceinline__ void step4_hist(const f2 (&yr)[4], const f2 (&yi)[4], const f2 (&hr)[3], const f2 (&hi)[3])
+    {
+        static_assert(SL == AMPS_SLICER_EXACT, "spec D only");
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const f2 p1r = g >= 1 ? yr[g - 1] : hr[0], p1i = g >= 1 ? yi[g - 1] : hi[0];
+            const f2 p3r = g >= 3 ? yr[g - 3] : hr[2 - g], p3i = g >= 3 ? yi[g - 3] : hi[2 - g];
+            const f2 it = __builtin_elementwise_fma(yi[g], p1r, -(yr[g] * p1i));       // Im(y conj(y[n-1]))
+            const f2 ic = __builtin_elementwise_fma(yi[g], p3r, -(yr[g] * p3i));       // Im(y conj(y[n-3]))
+            sx[0] = __builtin_amdgcn_alignbit(sx[0], __float_as_uint(yi[g].x), 31);
+            sx[1] = __builtin_amdgcn_alignbit(sx[1], __float_as_uint(yi[g].y), 31);
+            st[0] = __builtin_amdgcn_alignbit(st[0], __float_as_uint(it.x), 31);
+            st[1] = __builtin_amdgcn_alignbit(st[1], __float_as_uint(it.y), 31);
+            gw[0] = __builtin_amdgcn_alignbit(gw[0], __float_as_uint(ic.x), 31);
+            gw[1] = __builtin_amdgcn_alignbit(gw[1], __float_as_uint(ic.y), 31);
+        }
+    }
     // the ring word of the 32 frames just completed (oldest frame at bit 0)
     __device__ __forceinline__ uint32_t word(int e)
     {
@@ -558,10 +584,26 @@ template <int SL, bool IQ> struct ChzSlicer {
     uint32_t hold[NP][2][4];                                      // finished ring words waiting for their 16-byte store
     int nheld;
     uint64_t mask32;
+    // spec D: the four frames of the half-batch in work and of the one before it, per channel pair (step4_hist); only frames 1..3 of
+    // the older buffer are ever read again, so what stays live across a time step is what the members (pr, pi, h2, h3) used to hold
+    static constexpr bool PINGPONG = !IQ && SL == AMPS_SLICER_EXACT;
+    f2 Yr[PINGPONG ? 2 : 1][NP][NB], Yi[PINGPONG ? 2 : 1][NP][NB];
+    __device__ __forceinline__ void clear_frames()
+    {
+        if constexpr (PINGPONG) {
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int j = 0; j < NP; j++)
+#pragma unroll
+                    for (int g = 0; g < NB; g++) { Yr[b][j][g] = (f2){ 0.f, 0.f }; Yi[b][j][g] = (f2){ 0.f, 0.f }; }
+        }
+    }
     __device__ __forceinline__ void init(const ChzArgs &a, int wf, int lane)
     {
         nheld = 0;
         mask32 = 2ull * a.ring_words - 1;
+        clear_frames();
 #pragma unroll
         for (int j = 0; j < NP; j++) {
             S[j].reset();
@@ -585,7 +627,9 @@ template <int SL, bool IQ> struct ChzSlicer {
     // merge through which the compiler carried the whole slicer state in a second register set: ~50 v_mov per time step and wave
     // (8 % of the kernel's VALU instructions) for branches taken once in eight steps or twice per launch.  The role's loop now runs
     // seven KIND-1 steps and one KIND-2 step per word, and KIND 0 only at the two ends of a workgroup's range.
-    template <int KIND = 0>
+    // PAR = parity of the time step (spec D: which of the two frame buffers this half-batch is read into; the other one holds
+    // the half-batch before it.  Every half-batch between the first and the last sliced one is sliced, in consecutive time steps.)
+    template <int KIND = 0, int PAR = 0>
     __device__ __forceinline__ void half(const ChzArgs &a, const cf2 *buf, int64_t fs, int64_t f0, int64_t f1, int hs)
     {
         const int64_t F = fs + (int64_t)NB * hs;          // first frame of the half-batch (multiple of 4)
@@ -593,6 +637,20 @@ template <int SL, bool IQ> struct ChzSlicer {
 #pragma unroll
         for (int j = 0; j < NP; j++) {
             if (!pair_on[j]) continue;
+            if constexpr (PINGPONG) {
+                f2 (&yr)[NB] = Yr[PAR][j];
+                f2 (&yi)[NB] = Yi[PAR][j];
+#pragma unroll
+                for (int g = 0; g < NB; g++) {
+                    const float *q = Af + pbase[j] + g * CHZ_FBF;
+                    yr[g] = (f2){ q[0], q[64] };
+                    yi[g] = (f2){ q[128], q[192] };
+                }
+                const f2 hr[3] = { Yr[PAR ^ 1][j][3], Yr[PAR ^ 1][j][2], Yr[PAR ^ 1][j][1] };
+                const f2 hi[3] = { Yi[PAR ^ 1][j][3], Yi[PAR ^ 1][j][2], Yi[PAR ^ 1][j][1] };
+                S[j].step4_hist(yr, yi, hr, hi);
+                continue;
+            }
             f2 yr[NB], yi[NB];
 #pragma unroll
             for (int g = 0; g < NB; g++) {
@@ -627,6 +685,7 @@ template <int SL, bool IQ> struct ChzSlicer {
                 asm volatile("" ::: "memory");            // the state they leave is that of a fresh stream (a real branch, twice per launch)
 #pragma unroll
                 for (int j = 0; j < NP; j++) S[j].reset();
+                clear_frames();
             }
             if constexpr (SL == AMPS_SLICER_EXACT) {
                 // the word boundary inside the pre-roll (f0 - 1): latch the previous-word state the first real word needs
@@ -771,7 +830,9 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
     if (role == 0) {
         // ------------------------------------------------------------------ fold role
         const int t = tid & 255;
-        const ChzIn in{ a.block, a.carry, (int64_t)a.hist, (int64_t)a.carry_len - (int64_t)a.hist, (int64_t)a.carry_len, (int64_t)a.nsamp };
+        const int64_t lead0 = (int64_t)a.carry_len - (int64_t)a.hist;
+        const int64_t fl = ((int64_t)a.nsamp - CHZ_D + lead0) / CHZ_D;      // floor for the non-negative values the FAST path sees
+        const ChzIn in{ a.block, a.carry, (int64_t)a.hist, lead0, (int64_t)a.carry_len, (int64_t)a.nsamp, (uint32_t)(fl < 0 ? 0 : fl) };
         cf2 coef[4][P / 2];
 #pragma unroll
         for (int j = 0; j < 4; j++)
@@ -834,7 +895,7 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
         };
         constexpr int PERIOD = (P + 4) / 2;                       // half-steps until the ring is back where it started (6)
         static_assert(PERIOD == 6, "the unrolled loop below is written for P = 8");
-        auto run_steps = [&](auto edgec, int hb, int he) {        // half-steps [hb, he); hb is a multiple of the ring's period
+        auto run_steps = [&](auto edgec, int hb, int he) __attribute__((always_inline)) {        // half-steps [hb, he); hb is a multiple of the ring's period
             for (int h = hb; h < he; h += PERIOD) {
                 half_step(std::integral_constant<int, 0>{}, edgec, h);
                 if (h + 1 >= he) break;
@@ -896,28 +957,47 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
             // time step i slices half-batch hs = i - 3 and transforms h3 = i - 2.  STEADY steps -- 2 <= hs <= nh - 2: real frames, not
             // the range's last half-batch, h3 inside the range -- run without any of the rare-case tests (ChzSlicer::half<1 / 2>);
             // a 32-frame word completes when hs = 1 (mod 8), i.e. in the last step of every group of eight that starts at i = 5
-            auto step = [&](auto kindc, int i) {
-                constexpr int KIND = decltype(kindc)::value;
+            auto step = [&](auto kindc, auto parc, int i) __attribute__((always_inline)) {
+                constexpr int KIND = decltype(kindc)::value, PAR = decltype(parc)::value;   // PAR = i & 1
                 const int hs = i - 3, h3 = i - 2;
                 CHZ_STAMP(i, 0);
-                if (KIND != 0 || (hs >= 0 && hs < nh)) slicer.template half<KIND>(a, buf, fs, f0, f1, hs);
+                if (KIND != 0 || (hs >= 0 && hs < nh)) slicer.template half<KIND, PAR>(a, buf, fs, f0, f1, hs);
                 CHZ_STAMP(i, 1);
                 if constexpr (!P3_WITH_P2) { if ((KIND != 0 || (h3 >= 0 && h3 < nh)) && p3_on) chz_p3(buf + ((h3 & (CHZ_SLOTS - 1)) * NB + p3_f) * CHZ_FB, tw3, p3_i); }
                 CHZ_STAMP(i, 3);
                 __syncthreads();
                 CHZ_STAMP(i, 4);
             };
-            constexpr int I_FIRST = IQ ? 3 + 2 : 5;               // first steady step (hs = 2)
+            constexpr int I_FIRST = IQ ? 3 + 2 : 5;               // first steady step (hs = 2); ODD, and a group is eight steps: the parities below
+            static_assert((I_FIRST & 1) == 1, "parity of the steady groups");
             const int i_last = nh + 1;                            // last steady step (hs = nh - 2, h3 = nh - 1)
+            using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
+            using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
+            // Every step's parity is a compile-time constant, the edge steps' too: a run-time parity at either end would keep BOTH
+            // frame buffers of the slicer alive across the whole steady loop (24 VGPRs: measured as spills in the word step, +10 %).
             int i = 0;
-            for (; i < nsteps && i < I_FIRST; i++) step(std::integral_constant<int, 0>{}, i);
+            static_assert(I_FIRST == 5, "the five edge steps in front of the steady groups are written out");
+            if (i < nsteps) { step(K0{}, P0{}, i); i++; }
+            if (i < nsteps) { step(K0{}, P1{}, i); i++; }
+            if (i < nsteps) { step(K0{}, P0{}, i); i++; }
+            if (i < nsteps) { step(K0{}, P1{}, i); i++; }
+            if (i < nsteps) { step(K0{}, P0{}, i); i++; }
             while (i + 7 <= i_last) {
+                // seven plain steps and the one that completes a word; two steps per loop round so that the time step's parity -- which
+                // of the slicer's two frame buffers is written -- is a compile-time constant (all eight as straight-line code: 15
+                // spilled VGPRs)
 #pragma unroll 1
-                for (int k = 0; k < 7; k++) step(std::integral_constant<int, 1>{}, i + k);   // (all eight as straight-line code: 15 spilled VGPRs, no fewer moves)
-                step(std::integral_constant<int, 2>{}, i + 7);
+                for (int k = 0; k < 6; k += 2) { step(K1{}, P1{}, i + k); step(K1{}, P0{}, i + k + 1); }
+                step(K1{}, P1{}, i + 6);
+                step(K2{}, P0{}, i + 7);
                 i += 8;
             }
-            for (; i < nsteps; i++) step(std::integral_constant<int, 0>{}, i);
+            // (i is odd here -- I_FIRST + 8 n -- or the range was shorter than the five edge steps and nothing is left)
+            while (i < nsteps) {
+                step(K0{}, P1{}, i); i++;
+                if (i >= nsteps) break;
+                step(K0{}, P0{}, i); i++;
+            }
         }
         CHZ_TL_FLUSH;
     }

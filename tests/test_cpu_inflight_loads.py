@@ -109,7 +109,8 @@ def test_scanner_sees_a_planted_hazard():
     assert len(res) == 1 and len(res[0][3]) == 1 and "v_mov_b64" in res[0][3][0][3]
 
 
-def test_no_register_with_a_load_in_flight_is_touched():
+@pytest.fixture(scope="module")
+def asm_text():
     if not os.path.exists(build.hipcc()):
         pytest.skip("hipcc not installed")
     flags = [f for f in build.HIPCC_FLAGS if f not in ("-fPIC", "-shared")]
@@ -118,8 +119,58 @@ def test_no_register_with_a_load_in_flight_is_touched():
         subprocess.run([build.hipcc()] + flags + ["--cuda-device-only", "-S", "-I" + os.path.join(build._ROOT, "include"), "-I" + build.CSRC,
                                                   os.path.join(build.CSRC, "amps_recc.hip"), "-o", out],
                        check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        res = scan(open(out).read())
+        return open(out).read()
+
+
+def test_no_register_with_a_load_in_flight_is_touched(asm_text):
+    res = scan(asm_text)
     assert len(res) == 5, [r[0] for r in res]                      # the unfused form and the four slicer specs
     for name, nloads, nwaits, issues in res:
         assert nloads == 48 and nwaits == 6, (name, nloads, nwaits)   # six unrolled half-steps of eight loads
         assert not issues, (name, issues[:4])
+
+
+def role_bodies_with_scratch(asm):
+    """Per chz12_kernel instantiation: the basic blocks that are the body of a role -- recognised by their arithmetic: a fold step
+    (>= 100 v_pk_fma_f32), a radix-16 pass (>= 60 v_pk_add_f32) or a slicer step (>= 20 v_alignbit_b32) -- and contain a scratch
+    instruction.  Round 5's spec D slicer (two frame buffers used alternately) lets the compiler spill a few row addresses that are
+    reloaded once per 128 frames; that is fine ONLY as long as no role body touches scratch: a first version that did spilled inside
+    the word step and was 10 % slower (profiles/EXPERIMENTS.md)."""
+    txt = asm.split("\n")
+    bad, i = [], 0
+    while i < len(txt):
+        m = re.match(r"^(_ZN4amps12chz12_kernel\w+):", txt[i])
+        if not m:
+            i += 1
+            continue
+        j = i
+        while j < len(txt) and not txt[j].startswith(".Lfunc_end"):
+            j += 1
+        cur, counts = None, {}
+        for l in txt[i:j]:
+            lm = re.match(r"^(\.LBB\d+_\d+):", l)
+            if lm:
+                cur = lm.group(1)
+                counts[cur] = {"fma": 0, "add": 0, "align": 0, "scratch": 0}
+                continue
+            if cur is None:
+                continue
+            t = l.strip()
+            c = counts[cur]
+            c["fma"] += t.startswith("v_pk_fma_f32")
+            c["add"] += t.startswith("v_pk_add_f32")
+            c["align"] += t.startswith("v_alignbit_b32")
+            c["scratch"] += t.startswith("scratch_")
+        bad += [(m.group(1), b, c) for b, c in counts.items() if c["scratch"] and (c["fma"] >= 100 or c["add"] >= 60 or c["align"] >= 20)]
+        i = j
+    return bad
+
+
+def test_scratch_scanner_sees_a_planted_spill():
+    body = ["v_alignbit_b32 v1, v2, v3, 31"] * 24
+    asm = "\n".join(["_ZN4amps12chz12_kernelXX:", ".LBB0_1:"] + body + [".LBB0_2:"] + body + ["scratch_load_dword v0, off, off"] + [".Lfunc_end0:"])
+    assert [b for _, b, _ in role_bodies_with_scratch(asm)] == [".LBB0_2"]
+
+
+def test_no_role_body_of_the_filter_bank_touches_scratch(asm_text):
+    assert role_bodies_with_scratch(asm_text) == []

@@ -28,7 +28,10 @@ def _one(res, prefix):
 
 def test_filter_bank_kernel_budget(res):
     for name, r in _one(res, "void amps::chz12_kernel<8, ").items():
-        assert r["vgprs"] <= 168 and r["scratch_bytes_per_lane"] == 0 and r["vgpr_spill"] == 0, (name, r)
+        # spec D (<8, 3>, round 5: the slicer's two alternating frame buffers): a handful of row addresses live in scratch and are
+        # reloaded once per 128 frames -- no role body touches scratch (tests/test_cpu_inflight_loads.py scans the assembly for that)
+        spill_ok = 16 if "<8, 3>" in name else 0
+        assert r["vgprs"] <= 168 and r["scratch_bytes_per_lane"] <= 4 * spill_ok and r["vgpr_spill"] <= spill_ok, (name, r)
         assert r["waves_per_simd"] == 3, (name, r)                     # 12 waves per workgroup, one workgroup per CU
         assert r["lds_bytes"] <= 160 * 1024, (name, r)                 # one workgroup per CU owns the LDS (16 frame buffers)
 
