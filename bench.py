@@ -777,7 +777,7 @@ def main(argv=None):
         sec_steps = min(a.steps, 2000)
         sec, sec_base = run_workload(a.secondary, a, torch, dev, None, 0, 1, local, a.slicer, sec_steps, a.warmup)
         out["secondary"] = {"value": sec["value"], "unit": "Msym/s", "steps": sec_steps, "ms_per_step": sec["ms_per_step"], "config": sec["config"],
-                            "roofline": sec["roofline"], "roofline_compute": sec["roofline_compute"]}
+                            "roofline": sec["roofline"], "roofline_compute": sec["roofline_compute"], "power": sec.get("power")}
         if iq_base is None:
             iq_base = sec_base
     if world == 1 and a.secondary != "none" and "secondary" in out and not a.no_latency:
