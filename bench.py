@@ -286,7 +286,7 @@ class SmiSampler:
         import threading
         self.exe = shutil.which("rocm-smi")
         self.device, self.period = device, period
-        self.samples, self._stop = [], threading.Event()
+        self.samples, self._stop, self.other_clocks = [], threading.Event(), {}
         self._t = threading.Thread(target=self._run, daemon=True) if self.exe else None
 
     def _one(self):
@@ -296,10 +296,16 @@ class SmiSampler:
                                  stderr=subprocess.DEVNULL, timeout=5, text=True).stdout
             card = next(iter(json.loads(out).values()))
             power = next((float(v) for k, v in card.items() if "Power" in k and "(W)" in k), None)
-            sclk = next((v for k, v in card.items() if k.startswith("sclk")), None)
-            mhz = float("".join(ch for ch in str(sclk) if ch.isdigit() or ch == ".")) if sclk else None
+
+            def clock(name):
+                v = next((v for k, v in card.items() if k.startswith(name)), None)
+                digits = "".join(ch for ch in str(v) if ch.isdigit() or ch == ".") if v else ""
+                return float(digits) if digits else None
+            mhz = clock("sclk")
             if power is not None and mhz is not None:
                 self.samples.append((power, mhz))
+                # memory and fabric clocks beside the shader clock: what an HBM-bound kernel's box-to-box spread has to be read against
+                self.other_clocks = {k: clock(k) for k in ("mclk", "fclk", "socclk") if clock(k) is not None}
         except Exception:
             pass
 
@@ -328,7 +334,7 @@ class SmiSampler:
         p = [x[0] for x in self.samples]
         f = [x[1] for x in self.samples]
         return {"package_w_mean": round(sum(p) / len(p), 1), "package_w_max": round(max(p), 1), "sclk_mhz_mean": round(sum(f) / len(f), 1),
-                "samples": len(p), "source": "rocm-smi --showpower --showclocks every %.1f s during the timed region" % self.period}
+                "other_clocks_mhz": self.other_clocks, "samples": len(p), "source": "rocm-smi --showpower --showclocks every %.1f s during the timed region" % self.period}
 
 
 # ----------------------------------------------------------------------------------------------------- one workload
@@ -542,7 +548,7 @@ def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, w
                 def mean(k):
                     return round(sum(x[k] for x in sm) / len(sm), 1)
                 power = {"sustained": False, "package_w_mean": mean(0), "package_w_max": round(max(x[0] for x in sm), 1), "sclk_mhz_mean": mean(1),
-                         "sclk_mhz_min": round(min(x[1] for x in sm), 1), "samples": len(sm),
+                         "sclk_mhz_min": round(min(x[1] for x in sm), 1), "other_clocks_mhz": short_smi.other_clocks, "samples": len(sm),
                          "source": "rocm-smi --showpower --showclocks polled back to back from the prewarm, through the warmup and the timed region (shorter "
                                    "than one rocm-smi call), to the end of ~0.5 s of untimed steps of the same workload behind it"}
     if dist is not None:
