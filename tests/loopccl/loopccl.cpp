@@ -56,6 +56,7 @@ struct Comm {
 thread_local int g_depth = 0;
 thread_local Comm *g_group_comm = nullptr;
 thread_local hipStream_t g_group_stream = nullptr;
+Comm *g_only_comm = nullptr;                                  // the process's communicator (the tests make one per process): who an EMPTY group belongs to
 
 long env_ms(const char *name, long dflt) { const char *v = std::getenv(name); return v && *v ? std::atol(v) : dflt; }
 size_t dtype_size(int t) { switch (t) { case 0: case 1: return 1; case 2: case 3: case 7: return 4; case 4: case 5: case 8: return 8; case 6: case 9: return 2; default: return 0; } }
@@ -121,7 +122,7 @@ int transfer(Comm *c, int src, uint32_t dst_mask, const void *from, void *to, si
 int run_group(Comm *c, hipStream_t st)
 {
     if (c->pending.size() > MAXOPS) return BAD_USE;
-    if (hipStreamSynchronize(st) != hipSuccess) return HIP_ERR;
+    if (st && hipStreamSynchronize(st) != hipSuccess) return HIP_ERR;
     auto &mine = c->shm->table[c->rank];
     mine.n = (uint32_t)c->pending.size();
     for (size_t i = 0; i < c->pending.size(); i++) mine.ops[i] = { c->pending[i].kind, c->pending[i].peer, c->pending[i].bytes };
@@ -201,6 +202,7 @@ int ncclCommInitRank(void **comm, int nranks, ncclUniqueId id, int rank)
     }
     if (barrier(c)) { munmap(p, sizeof(Shm)); delete c; return SYS_ERR; }
     if (rank == 0) unlink(id.internal);                               // everybody has it mapped: the name can go
+    g_only_comm = c;
     *comm = c;
     return OK;
 }
@@ -236,9 +238,14 @@ int ncclGroupEnd()
     if (g_depth <= 0) return BAD_USE;
     if (--g_depth) return OK;
     Comm *c = g_group_comm;
+    hipStream_t st = g_group_stream;
     g_group_comm = nullptr;
-    if (!c) return OK;                                               // an empty group (a one-rank scatter)
-    return run_group(c, g_group_stream);
+    g_group_stream = nullptr;
+    // A group in which THIS rank posted nothing (the library's scatter on a rank whose chunk is empty, or with one rank) still has to
+    // take part in the others' exchange -- they wait at the barriers: it belongs to the process's one communicator.
+    if (!c) c = g_only_comm;
+    if (!c) return OK;
+    return run_group(c, st);
 }
 static int p2p(uint32_t kind, void *ptr, size_t count, int dtype, int peer, void *comm, hipStream_t st)
 {
@@ -254,10 +261,6 @@ static int p2p(uint32_t kind, void *ptr, size_t count, int dtype, int peer, void
 int ncclSend(const void *send, size_t count, int dtype, int peer, void *comm, hipStream_t st) { return p2p(1, (void *)send, count, dtype, peer, comm, st); }
 int ncclRecv(void *recv, size_t count, int dtype, int peer, void *comm, hipStream_t st) { return p2p(2, recv, count, dtype, peer, comm, st); }
 
-// A group in which THIS rank has nothing to send or receive still has to take part in the others' exchange (they wait at the
-// barriers): the library's scatter posts an empty group on ranks whose chunk is empty only when every chunk is -- so an empty group
-// means "nobody moves anything" and needs no barrier.
-
 static void release_hangs(Comm *c) { for (Hang *h : c->hangs) h->release.store(1, std::memory_order_release); }
 int ncclCommAbort(void *comm)
 {
@@ -266,6 +269,7 @@ int ncclCommAbort(void *comm)
     c->shm->abort_flag.store(1, std::memory_order_release);
     release_hangs(c);
     c->broken = true;
+    if (g_only_comm == c) g_only_comm = nullptr;
     return OK;                                                       // (the object is leaked on purpose: a sleeper may still look at its Hang)
 }
 int ncclCommDestroy(void *comm)
@@ -273,6 +277,7 @@ int ncclCommDestroy(void *comm)
     Comm *c = (Comm *)comm;
     if (!c) return BAD_ARG;
     release_hangs(c);
+    if (g_only_comm == c) g_only_comm = nullptr;
     munmap(c->shm, sizeof(Shm));
     c->shm = nullptr;
     return OK;

@@ -83,6 +83,9 @@ def main():
                 pushed.append(r.push_wideband_dist(blk, None, a.root, a.mode))
             tail = np.zeros(64 * D, np.complex64) if x is not None else None
             pushed.append(r.push_wideband_dist(tail, None, a.root, a.mode))
+            # a block so short that the scatter leaves most ranks with an EMPTY chunk (they post no receive at all)
+            crumb = np.zeros(100, np.complex64) if x is not None else None
+            pushed.append(r.push_wideband_dist(crumb, None, a.root, a.mode))
             out["pushed"] = pushed
             recs = r.drain_gather(root=a.root, cap=4096)
             out["gathered"] = int(len(recs))

@@ -72,7 +72,7 @@ def _run(stream, tmp_path, nranks, scenario, mode="broadcast", root=0, env_extra
 def test_ranks_reproduce_the_whole_band_records(stream, tmp_path, nranks, mode, root):
     res = _run(stream, tmp_path, nranks, "dist", mode, root)
     n = stream["n"]
-    want_pushed = [2000000, 3000064, n - 5000064, 64 * D]
+    want_pushed = [2000000, 3000064, n - 5000064, 64 * D, 100]
     for r, o in enumerate(res):
         assert o["init"] == 0
         assert o["pushed"] == want_pushed                      # the ROOT's block sizes arrived on every rank (the others passed none)
@@ -81,7 +81,7 @@ def test_ranks_reproduce_the_whole_band_records(stream, tmp_path, nranks, mode, 
         assert i["max_samples_per_push"] == (n // D + 72) * D and i["max_bursts_per_gather"] == 96      # min / max over the ranks
         assert "loopccl" in i["library"] and len(i["device_uuid"]) == 32
         ia = o["info_after"]
-        assert ia["last_mode"] == mode and ia["collectives_timed"] == 4 and ia["collective_bytes"] == 8 * sum(want_pushed) and ia["collective_ms"] > 0
+        assert ia["last_mode"] == mode and ia["collectives_timed"] == 5 and ia["collective_bytes"] == 8 * sum(want_pushed) and ia["collective_ms"] > 0
         assert o["gathered"] == (len(stream["whole"]) if r == root else 0) and o["second_gather"] == 0
     got = np.load(tmp_path / "gathered.npy")
     assert got.tobytes() == stream["whole"].tobytes()
@@ -95,7 +95,7 @@ def test_the_smallest_rank_bounds_the_push_and_an_oversize_block_is_everybodys_e
     for r, o in enumerate(res):
         assert o["info"]["max_samples_per_push"] == ((n // 3) // D + 72) * D
         assert o["events"][0] == ["oversize", -errno.E2BIG if r == 0 else -errno.EREMOTEIO]
-        assert o["pushed"] == [n // 3, n // 3, n - 2 * (n // 3), 64 * D]
+        assert o["pushed"] == [n // 3, n // 3, n - 2 * (n // 3), 64 * D, 100]
     got = np.load(tmp_path / "gathered.npy")
     assert got.tobytes() == stream["whole"].tobytes()           # other cuts of the same stream: the same records
 
