@@ -130,6 +130,23 @@ struct amps_recc {
 
 namespace {
 
+// a packed record (recc_decode.hip.h: decode_core_store_packed, 216 bytes) -> the ABI's amps_recc_burst_t: the two bit arrays back to
+// one byte per bit, eight output bytes per packed byte through a table
+inline void expand_packed_record(amps_recc_burst_t *dst, const uint8_t *src)
+{
+    static const std::vector<uint64_t> lut = [] {
+        std::vector<uint64_t> t(256);
+        for (int v = 0; v < 256; v++) { uint64_t w = 0; for (int i = 0; i < 8; i++) w |= (uint64_t)((v >> i) & 1) << (8 * i); t[v] = w; }
+        return t;
+    }();
+    uint8_t *d = (uint8_t *)dst;
+    std::memcpy(d, src, REC_RAW_OFF);
+    const uint8_t *raw = src + 13 * 4, *dec = src + 24 * 4;
+    for (int k = 0; k < (REC_DEC_OFF - REC_RAW_OFF) / 8; k++) std::memcpy(d + REC_RAW_OFF + 8 * k, &lut[raw[k]], 8);            // 42 x 8 = 336 bytes
+    for (int k = 0; k < (REC_TAIL_OFF - REC_DEC_OFF + 7) / 8; k++) std::memcpy(d + REC_DEC_OFF + 8 * k, &lut[dec[k]], 8);        // 32 x 8: 4 bytes into the tail ...
+    std::memcpy(d + REC_TAIL_OFF, src + 32 * 4, sizeof(amps_recc_burst_t) - REC_TAIL_OFF);                                       // ... which is written last
+}
+
 template <typename T> int dev_alloc(T **p, size_t n)
 {
     if (n == 0) n = 1;
@@ -553,8 +570,8 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
     rc |= dev_alloc(&h->burst_chan_dev, cfg->max_bursts);
     rc |= dev_alloc(&h->nbursts_dev, 1);
     step("symbol seam buffers allocated");
-    // result records live in mapped, pinned host memory (zero copy: 728 B per burst over PCIe while the
-    // kernels run); h->records is the device-side view of the same allocation
+    // result records live in mapped, pinned host memory (zero copy: PACKED_RECORD_BYTES = 216 per burst over PCIe while the
+    // kernels run, expanded to the ABI's 728 by drain_end_impl); h->records is the device-side view of the same allocation
     for (int b = 0; b < 2; b++)
         if (hipHostMalloc((void **)&h->rec_host_buf[b], sizeof(amps_recc_burst_t) * (size_t)cfg->max_bursts, hipHostMallocMapped) != hipSuccess ||
             hipHostGetDevicePointer((void **)&h->records_buf[b], h->rec_host_buf[b], 0) != hipSuccess) rc |= -ENOMEM;
@@ -1167,11 +1184,17 @@ static int drain_end_impl(amps_recc_t *h, amps_recc_burst_t *out, uint8_t *burst
         // order by (channel, position) through compact 16-byte keys, then gather once into the caller's buffer
         struct Key { uint64_t k; uint32_t i; };
         std::vector<Key> keys(n);
-        const amps_recc_burst_t *r = h->rec_host_buf[b];
-        for (uint32_t i = 0; i < n; i++) keys[i] = { ((uint64_t)r[i].channel << CAPQ_POS_BITS) | (r[i].position & ((1ull << CAPQ_POS_BITS) - 1)), i };
+        // (packed: PACKED_RECORD_BYTES each, the bit arrays as bits -- recc_decode.hip.h; channel and position sit in the first 16 bytes)
+        const uint8_t *r = (const uint8_t *)h->rec_host_buf[b];
+        for (uint32_t i = 0; i < n; i++) {
+            uint32_t ch; uint64_t pos;
+            std::memcpy(&ch, r + (size_t)i * PACKED_RECORD_BYTES + offsetof(amps_recc_burst_t, channel), 4);
+            std::memcpy(&pos, r + (size_t)i * PACKED_RECORD_BYTES + offsetof(amps_recc_burst_t, position), 8);
+            keys[i] = { ((uint64_t)ch << CAPQ_POS_BITS) | (pos & ((1ull << CAPQ_POS_BITS) - 1)), i };
+        }
         std::sort(keys.begin(), keys.end(), [](const Key &x, const Key &y) { return x.k < y.k; });
         size_t k = std::min<size_t>(n, cap);
-        if (out) for (size_t i = 0; i < k; i++) std::memcpy(&out[i], &r[keys[i].i], sizeof(amps_recc_burst_t));
+        if (out) for (size_t i = 0; i < k; i++) expand_packed_record(&out[i], r + (size_t)keys[i].i * PACKED_RECORD_BYTES);
         if (out && h->chz.enabled && h->chz.groups > 1)               // rows of a channel group -> channel numbers of the band selection
             for (size_t i = 0; i < k; i++) out[i].channel = out[i].channel < h->chz.row2chan.size() ? h->chz.row2chan[out[i].channel] : out[i].channel;
         if (bursts_out && h->bsym_host_buf[b])

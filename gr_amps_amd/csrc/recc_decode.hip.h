@@ -404,6 +404,41 @@ __device__ __forceinline__ void decode_core_store(const DecodeCore &s, amps_recc
     for (int i = lane; i < (int)(sizeof(amps_recc_burst_t) / 4); i += 64) ((uint32_t *)out)[i] = ((const uint32_t *)&s.rec)[i];
 }
 
+// ---- the record on its way to the host (round 5).  The capture kernels write their records straight into mapped, pinned HOST memory;
+// 588 of a record's 728 bytes are the one-byte-per-bit arrays word_raw[7][48] and word_dec[7][36] the reference's own layout asks for
+// (lib/recc_decode_impl.cc:92-95).  1664 records per push of the channel-major bench are 1.2 MB of 728-byte PCIe writes that the kernel
+// cannot retire before they have crossed the link: 0.050 ms of "resolve + capture + decode" there was mostly that.  So the bits travel
+// as bits -- PACKED_RECORD_BYTES = 216 instead of 728 -- and amps_recc_drain expands them while it gathers the sorted records into the
+// caller's buffer anyway (expand_packed_record: one 8-byte table entry per packed byte).  Layout, in dwords:
+//    0 .. 12   the record's first 52 bytes as they are (channel .. first_valid_rep)
+//   13 .. 23   word_raw: bit 8 j + i of dword 13 + g = byte 32 g + 4 j + i of the array (bytes past the array's 336: don't care)
+//   24 .. 31   word_dec likewise (252 bytes)
+//   32 .. 53   the record's last 88 bytes as they are (a_F .. _pad4)
+constexpr int PACKED_RECORD_BYTES = 216;
+constexpr int REC_RAW_OFF = 52, REC_DEC_OFF = 388, REC_TAIL_OFF = 640;
+static_assert(offsetof(amps_recc_burst_t, word_raw) == REC_RAW_OFF && offsetof(amps_recc_burst_t, word_dec) == REC_DEC_OFF &&
+              offsetof(amps_recc_burst_t, a_F) == REC_TAIL_OFF && sizeof(amps_recc_burst_t) - REC_TAIL_OFF == 88, "packed record layout");
+__device__ __forceinline__ void decode_core_store_packed(const DecodeCore &s, uint32_t *__restrict__ out, int lane)
+{
+    const uint32_t *rec = (const uint32_t *)&s.rec;
+    if (lane < PACKED_RECORD_BYTES / 4) {
+        uint32_t v;
+        if (lane < 13) v = rec[lane];
+        else if (lane >= 32) v = rec[REC_TAIL_OFF / 4 + (lane - 32)];
+        else {
+            const uint32_t *src = rec + (lane < 24 ? REC_RAW_OFF / 4 + 8 * (lane - 13) : REC_DEC_OFF / 4 + 8 * (lane - 24));
+            v = 0u;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                // bytes are 0 / 1: the multiply gathers their low bits into bits 24 .. 27 (no two partial products share a bit position)
+                // (the last group of either array runs a few bytes into the field behind it -- inside the record; those bits are don't-care)
+                v |= ((((src[j] & 0x01010101u) * 0x01020408u) >> 24) & 0xfu) << (4 * j);
+            }
+        }
+        out[lane] = v;
+    }
+}
+
 // Tl: optional stage stamps (scripts/ubench_decode.hip); NoTl compiles to nothing.
 struct NoTl { __device__ __forceinline__ void mark(int) {} };
 template <class Sync, class Tl = NoTl>

@@ -104,7 +104,7 @@ __device__ __forceinline__ void capture_decode_wave(const ResolveArgs &a, uint32
 __device__ __forceinline__ void capture_store_wave(const ResolveArgs &a, uint64_t nc, uint32_t slot, const uint64_t *scratch, int lane)
 {
     const DecodeCore &k = *(const DecodeCore *)scratch;
-    decode_core_store(k, a.records + slot, lane);
+    decode_core_store_packed(k, (uint32_t *)((uint8_t *)a.records + (size_t)slot * PACKED_RECORD_BYTES), lane);   // bits as bits over PCIe: expand_packed_record
     if (a.burst_syms) {
         const uint64_t *s_ring = scratch + (sizeof(DecodeCore) + 7) / 8;
         const uint64_t w0 = capture_first_word(nc, a.sps);
