@@ -80,7 +80,7 @@ struct amps_recc {
     bool list_clean[2] = { true, true };      // the device-side {nrecords, status} of the list are zero (or a launch that zeroes them is enqueued)
     // two record lists: pushes append to the current one; drain_begin closes it (and switches), drain_end collects it
     amps_recc_burst_t *rec_host_buf[2] = { nullptr, nullptr }, *records_buf[2] = { nullptr, nullptr };
-    uint8_t *bsym_host_buf[2] = { nullptr, nullptr }, *bsym_dev_buf[2] = { nullptr, nullptr };   // AMPS_RECC_FLAG_KEEP_BURSTS: [max_bursts][3374], mapped pinned
+    uint8_t *bsym_host_buf[2] = { nullptr, nullptr }, *bsym_dev_buf[2] = { nullptr, nullptr };   // AMPS_RECC_FLAG_KEEP_BURSTS: [max_bursts][PACKED_BURST_BYTES] (a bit per symbol; allocated for 3374 bytes each), mapped pinned
     uint32_t *nrecords_buf[2] = { nullptr, nullptr }, *status_buf[2] = { nullptr, nullptr };
     int cur_buf = 0, open_buf = -1;
     bool open_untouched = false;      // no push has been enqueued since drain_begin: the open list's device counters are still there (header cross-check)
@@ -145,6 +145,12 @@ inline void expand_packed_record(amps_recc_burst_t *dst, const uint8_t *src)
     for (int k = 0; k < (REC_DEC_OFF - REC_RAW_OFF) / 8; k++) std::memcpy(d + REC_RAW_OFF + 8 * k, &lut[raw[k]], 8);            // 42 x 8 = 336 bytes
     for (int k = 0; k < (REC_TAIL_OFF - REC_DEC_OFF + 7) / 8; k++) std::memcpy(d + REC_DEC_OFF + 8 * k, &lut[dec[k]], 8);        // 32 x 8: 4 bytes into the tail ...
     std::memcpy(d + REC_TAIL_OFF, src + 32 * 4, sizeof(amps_recc_burst_t) - REC_TAIL_OFF);                                       // ... which is written last
+}
+
+// the kept symbol blob: PACKED_BURST_BYTES of bits -> the 3374 bytes (values 0 / 1) gr::amps::recc publishes (lib/recc_impl.cc:126)
+inline void expand_packed_burst(uint8_t *dst, const uint8_t *src)
+{
+    for (int i = 0; i < AMPS_RECC_CAPTURE_SYMS; i++) dst[i] = (uint8_t)((src[i >> 3] >> (i & 7)) & 1u);
 }
 
 template <typename T> int dev_alloc(T **p, size_t n)
@@ -1199,7 +1205,7 @@ static int drain_end_impl(amps_recc_t *h, amps_recc_burst_t *out, uint8_t *burst
             for (size_t i = 0; i < k; i++) out[i].channel = out[i].channel < h->chz.row2chan.size() ? h->chz.row2chan[out[i].channel] : out[i].channel;
         if (bursts_out && h->bsym_host_buf[b])
             for (size_t i = 0; i < k; i++)
-                std::memcpy(bursts_out + i * AMPS_RECC_CAPTURE_SYMS, h->bsym_host_buf[b] + (size_t)keys[i].i * AMPS_RECC_CAPTURE_SYMS, AMPS_RECC_CAPTURE_SYMS);
+                expand_packed_burst(bursts_out + i * AMPS_RECC_CAPTURE_SYMS, h->bsym_host_buf[b] + (size_t)keys[i].i * PACKED_BURST_BYTES);
         *nout = k;
         if (n > cap) rc = -ENOSPC;
     }

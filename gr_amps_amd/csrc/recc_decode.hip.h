@@ -415,6 +415,7 @@ __device__ __forceinline__ void decode_core_store(const DecodeCore &s, amps_recc
 //   24 .. 31   word_dec likewise (252 bytes)
 //   32 .. 53   the record's last 88 bytes as they are (a_F .. _pad4)
 constexpr int PACKED_RECORD_BYTES = 216;
+constexpr int PACKED_BURST_BYTES = (AMPS_RECC_CAPTURE_SYMS + 31) / 32 * 4;   // 424: the kept 3374-symbol blob, a bit per symbol (recc_resolve.hip.h: capture_store_wave)
 constexpr int REC_RAW_OFF = 52, REC_DEC_OFF = 388, REC_TAIL_OFF = 640;
 static_assert(offsetof(amps_recc_burst_t, word_raw) == REC_RAW_OFF && offsetof(amps_recc_burst_t, word_dec) == REC_DEC_OFF &&
               offsetof(amps_recc_burst_t, a_F) == REC_TAIL_OFF && sizeof(amps_recc_burst_t) - REC_TAIL_OFF == 88, "packed record layout");

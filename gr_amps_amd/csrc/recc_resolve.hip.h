@@ -106,13 +106,22 @@ __device__ __forceinline__ void capture_store_wave(const ResolveArgs &a, uint64_
     const DecodeCore &k = *(const DecodeCore *)scratch;
     decode_core_store_packed(k, (uint32_t *)((uint8_t *)a.records + (size_t)slot * PACKED_RECORD_BYTES), lane);   // bits as bits over PCIe: expand_packed_record
     if (a.burst_syms) {
+        // the kept blob (AMPS_RECC_FLAG_KEEP_BURSTS) crosses PCIe as BITS too (round 5): symbol i = bit i of PACKED_BURST_BYTES, two
+        // dwords per lane instead of 53 single-byte stores; amps_recc_drain_bursts expands it to the 3374 bytes gr::amps::recc publishes
         const uint64_t *s_ring = scratch + (sizeof(DecodeCore) + 7) / 8;
         const uint64_t w0 = capture_first_word(nc, a.sps);
-        uint8_t *dst = a.burst_syms + (uint64_t)slot * AMPS_RECC_CAPTURE_SYMS;
-        for (int i = lane; i < AMPS_RECC_CAPTURE_SYMS; i += 64) {
-            const int kb = i >> 1, blk = kb < 7 + AMPS_RECC_WORD_BITS ? 1 : 2 + (kb - 7 - AMPS_RECC_WORD_BITS) / AMPS_RECC_WORD_BITS;   // tracking block of the symbol's bit
-            const uint64_t n = (uint64_t)((int64_t)nc + (int64_t)a.sps * (i + 1) + k.dly[blk]);
-            dst[i] = (uint8_t)((s_ring[(n >> 6) - w0] >> (n & 63)) & 1ull);
+        uint32_t *dst = (uint32_t *)(a.burst_syms + (uint64_t)slot * PACKED_BURST_BYTES);
+        for (int dw = lane; dw < PACKED_BURST_BYTES / 4; dw += 64) {
+            uint32_t word = 0u;
+            for (int j = 0; j < 32; j++) {
+                const int i = 32 * dw + j;
+                if (i < AMPS_RECC_CAPTURE_SYMS) {
+                    const int kb = i >> 1, blk = kb < 7 + AMPS_RECC_WORD_BITS ? 1 : 2 + (kb - 7 - AMPS_RECC_WORD_BITS) / AMPS_RECC_WORD_BITS;   // tracking block of the symbol's bit
+                    const uint64_t n = (uint64_t)((int64_t)nc + (int64_t)a.sps * (i + 1) + k.dly[blk]);
+                    word |= (uint32_t)((s_ring[(n >> 6) - w0] >> (n & 63)) & 1ull) << j;
+                }
+            }
+            dst[dw] = word;
         }
     }
 }
