@@ -189,6 +189,13 @@ __global__ __launch_bounds__(THREADS, 4) void recc_resolve_kernel(ResolveArgs a)
     RTL(0);
     const uint64_t span_hold = (uint64_t)a.sps * (AMPS_RECC_CAPTURE_SYMS + AMPS_RECC_TRIGGER_SYMS);
     const uint64_t span_done = (uint64_t)a.sps * (AMPS_RECC_CAPTURE_SYMS + 1) + (a.track ? AMPS_TRACK_BLOCKS : 0);   // + the most the sampling instants can move
+    // (the first batch's hit counts are fetched HERE, beside the channel's state: they used to be the third dependent global load of a
+    // workgroup's first 3 us)
+    const uint32_t n_first = [&]() -> uint32_t {
+        const uint64_t gs0 = (uint64_t)c * a.tiles_per_channel;
+        const uint32_t nch = (uint32_t)((gs0 + a.tiles_per_channel - 1) / a.span - gs0 / a.span) + 1;
+        return (uint32_t)tid < nch ? a.detcount[(uint64_t)c * a.max_chunks + (uint32_t)tid] : 0u;
+    }();
     uint64_t next_allowed = a.next_allowed[c];                        // uniform across the block
     uint64_t pend = a.pending[c];
     auto centre = [](uint64_t ei) -> uint64_t { return (ei >> 8) + (uint32_t)(ei & 0xff) / 2; };   // of the run of matching phases
@@ -211,6 +218,8 @@ __global__ __launch_bounds__(THREADS, 4) void recc_resolve_kernel(ResolveArgs a)
             __syncthreads();
         } else if (m) {
             for (uint32_t i0 = 0; i0 < m; i0 += CAP_WAVES) {
+                // (rotating the capture -> wave assignment by the channel, so that the workgroups sharing a CU do not all decode in their
+                // wave 0, was measured in round 5: 0.0311 against 0.0304 ms -- no gain, not kept)
                 const uint32_t i = i0 + (uint32_t)wv;
                 const bool mine = wv < CAP_WAVES && i < m;
                 uint64_t *scr = s_cap + (size_t)wv * resolve_cap_stride(a.cap_words);
@@ -254,7 +263,7 @@ __global__ __launch_bounds__(THREADS, 4) void recc_resolve_kernel(ResolveArgs a)
     for (uint32_t cb = 0; cb < nchunks; cb += THREADS) {
         // ---- compaction of up to THREADS segments into LDS, order preserved
         const uint32_t ch = cb + tid;
-        const uint32_t n = ch < nchunks ? cnt[ch] : 0u;
+        const uint32_t n = cb == 0 ? n_first : (ch < nchunks ? cnt[ch] : 0u);
         // inclusive scan of the counts: inside each wave by lane shifts, then the wave totals (two barriers; the first version
         // was a Hillis-Steele scan over the workgroup in LDS, seventeen)
         uint32_t incl = n;
