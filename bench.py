@@ -540,7 +540,7 @@ def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, w
             r.drain_begin()
         r.drain_end(copy=False)
         torch.cuda.synchronize()
-        if short_smi:
+        if short_smi and short_smi._t:                    # (no rocm-smi on the box: no poller thread, no `power`)
             short_smi._stop.set()
             short_smi._t.join(timeout=6)
             sm = short_smi.samples
