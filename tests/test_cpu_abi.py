@@ -58,6 +58,17 @@ def test_argument_validation_needs_no_gpu():
     n = C.c_size_t(0)
     assert L.amps_recc_drain(None, None, 0, C.byref(n)) == -22
     assert L.amps_recc_push_iq(None, None, 0, 0, 0) == -22
+    # the collective entry points (ABI 4) refuse a missing handle the same way, without touching a device or librccl
+    assert L.amps_recc_rccl_init(None, None, 1, 0) == -22
+    assert L.amps_recc_push_wideband_dist(None, None, 0, 0, 0, 0, C.byref(n)) == -22 and n.value == 0
+    assert L.amps_recc_push_wideband_bcast(None, None, 0, 0, 0) == -22
+    assert L.amps_recc_drain_gather(None, None, 0, C.byref(n), 0) == -22
+    assert L.amps_recc_rccl_abort(None) == -22 and L.amps_recc_rccl_set_timeout(None, 1000) == -22
+    info = capi.RcclInfo()
+    info.struct_size = C.sizeof(capi.RcclInfo)
+    assert L.amps_recc_rccl_info(None, C.byref(info)) == -22
+    for code, text in ((-110, b"RCCL timeout"), (-107, b"aborted"), (-121, b"another rank")):       # -ETIMEDOUT, -ENOTCONN, -EREMOTEIO
+        assert text in L.amps_recc_strerror(code)
 
 
 @pytest.mark.parametrize("kind", ["page_response", "registration", "origination"])
