@@ -130,15 +130,21 @@ struct amps_recc {
 
 namespace {
 
-// a packed record (recc_decode.hip.h: decode_core_store_packed, 216 bytes) -> the ABI's amps_recc_burst_t: the two bit arrays back to
-// one byte per bit, eight output bytes per packed byte through a table
-inline void expand_packed_record(amps_recc_burst_t *dst, const uint8_t *src)
+// bits -> bytes, eight at a time: table entry v = the eight bytes (0 / 1) of the bits of v, bit i in byte i
+inline const uint64_t *bit_bytes_lut()
 {
     static const std::vector<uint64_t> lut = [] {
         std::vector<uint64_t> t(256);
         for (int v = 0; v < 256; v++) { uint64_t w = 0; for (int i = 0; i < 8; i++) w |= (uint64_t)((v >> i) & 1) << (8 * i); t[v] = w; }
         return t;
     }();
+    return lut.data();
+}
+// a packed record (recc_decode.hip.h: decode_core_store_packed, 216 bytes) -> the ABI's amps_recc_burst_t: the two bit arrays back to
+// one byte per bit
+inline void expand_packed_record(amps_recc_burst_t *dst, const uint8_t *src)
+{
+    const uint64_t *lut = bit_bytes_lut();
     uint8_t *d = (uint8_t *)dst;
     std::memcpy(d, src, REC_RAW_OFF);
     const uint8_t *raw = src + 13 * 4, *dec = src + 24 * 4;
@@ -150,7 +156,10 @@ inline void expand_packed_record(amps_recc_burst_t *dst, const uint8_t *src)
 // the kept symbol blob: PACKED_BURST_BYTES of bits -> the 3374 bytes (values 0 / 1) gr::amps::recc publishes (lib/recc_impl.cc:126)
 inline void expand_packed_burst(uint8_t *dst, const uint8_t *src)
 {
-    for (int i = 0; i < AMPS_RECC_CAPTURE_SYMS; i++) dst[i] = (uint8_t)((src[i >> 3] >> (i & 7)) & 1u);
+    const uint64_t *lut = bit_bytes_lut();
+    constexpr int FULL = AMPS_RECC_CAPTURE_SYMS / 8;                                                                             // 421 whole bytes of bits
+    for (int k = 0; k < FULL; k++) std::memcpy(dst + 8 * k, &lut[src[k]], 8);
+    for (int i = 8 * FULL; i < AMPS_RECC_CAPTURE_SYMS; i++) dst[i] = (uint8_t)((src[i >> 3] >> (i & 7)) & 1u);                    // the last six symbols
 }
 
 template <typename T> int dev_alloc(T **p, size_t n)

@@ -20,8 +20,11 @@ for keep in (False, True):
             (r.drain_bursts() if keep else r.drain(copy=False))
         r.timing(reset=True)
         n = 0
+        import time
+        t0 = time.perf_counter()
         for _ in range(REP):
             r.push_iq(d)
             n += len((r.drain_bursts()[0] if keep else r.drain(copy=False)))
+        wall = (time.perf_counter() - t0) / REP * 1e3
         t = r.timing()
-        print("keep_bursts=%-5s records/push %6.1f resolve+capture+decode %.4f ms" % (keep, n / REP, t["ms_resolve"] / REP), flush=True)
+        print("keep_bursts=%-5s records/push %6.1f resolve+capture+decode %.4f ms   push + drain, host clock %.3f ms" % (keep, n / REP, t["ms_resolve"] / REP, wall), flush=True)

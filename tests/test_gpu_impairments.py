@@ -164,7 +164,10 @@ def test_wideband_seam_decodes_what_the_reference_chain_decodes(gpu, ppm, cfo):
         if _good(oracle.chain_iq400(y, 160e3, chunk=4096), *planted[c]):
             nref += 1
             assert out[False][c]
-    assert nref >= (len(chans) // 2 if cfo == 0 else 2), nref   # the restated chain loses ~40 % of the bursts at a 2 kHz carrier offset (profiles/r04/impairments.txt)
+    # (a floor against a vacuous comparison, not a property of the seam: at a 2 kHz carrier offset the restated chain's Mueller & Mueller
+    # loop locks or not on the last bits of rounding of the FFT-cut input -- 1 .. 5 of the 16 bursts from box to box (rocFFT picks its
+    # kernels per box); round 5 saw 1 once where the floor was 2)
+    assert nref >= (len(chans) // 2 if cfo == 0 else 1), nref
 
 
 def test_round4_golden_fixture_on_the_device(gpu):
