@@ -165,8 +165,9 @@ def test_wideband_seam_decodes_what_the_reference_chain_decodes(gpu, ppm, cfo):
             nref += 1
             assert out[False][c]
     # (a floor against a vacuous comparison, not a property of the seam: at a 2 kHz carrier offset the restated chain's Mueller & Mueller
-    # loop locks or not on the last bits of rounding of the FFT-cut input -- 1 .. 5 of the 16 bursts from box to box (rocFFT picks its
+    # loop locks or not on the last bits of rounding of the FFT-cut input -- 4, 3, 3 and once 1 of the 16 bursts on four boxes (rocFFT picks its
     # kernels per box); round 5 saw 1 once where the floor was 2)
+    print("restated chain decoded %d of %d" % (nref, len(chans)))            # (pytest -rP shows it)
     assert nref >= (len(chans) // 2 if cfo == 0 else 1), nref
 
 
