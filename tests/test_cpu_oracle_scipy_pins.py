@@ -46,3 +46,24 @@ def test_quadrature_demod_is_the_phase_step():
     d = oracle.quadrature_demod(iq)
     want = np.angle(iq[1:].astype(np.complex128) * np.conj(iq[:-1].astype(np.complex128)))
     assert np.abs(d[1:] - want).max() < 1e-5                                   # fast_atan2f: 255-entry table + linear interpolation
+
+
+def test_filter_bank_model_is_mix_filter_decimate_per_channel():
+    """The numpy model the GPU filter bank is held to (oracle/channelizer.py: weighted overlap-add + FFT, what chz12_kernel computes) IS, bin
+    by bin, the per-channel chain it replaces with another prototype: mix bin k to DC, FIR with the prototype, keep every 512th sample
+    -- freq_xlating_fir_filter_ccc's job (grc/recctest.grc:889-937) -- stated with scipy.signal.lfilter; and its prototype is scipy's
+    Kaiser-windowed sinc."""
+    from oracle import channelizer as cz
+    rng = np.random.default_rng(1)
+    M, D, P = 1024, 512, 8
+    n = D * 40
+    x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    Y = cz.channelize(x, P, M, D)
+    h = cz.design_taps(P, M)
+    w = signal.firwin(h.size, 13e3, window=("kaiser", 8.0), fs=M * 30e3)
+    assert np.abs(h - w / w.sum()).max() < 1e-15
+    nn = np.arange(n)
+    for k in (0, 5, 96, 511, 512, 927, 1023):
+        mixed = x * np.exp(-2j * np.pi * k * nn / M)
+        want = signal.lfilter(h[::-1], 1.0, mixed)[D - 1::D][:Y.shape[1]]       # frame m ends with sample (m + 1) D - 1
+        assert np.abs(Y[k] - want).max() < 1e-11 * np.abs(want).max(), k
