@@ -8,6 +8,12 @@ It replaces M instances of the reference's freq_xlating_fir_filter_ccc (grc/recc
 import numpy as np
 
 
+def cutoff_for_decim(D):
+    """The prototype's -6 dB point: 13 kHz behind the 2x oversampled bank (D = 512, 60 ksps per channel), 15 kHz at D = 768 (40 ksps,
+    two samples per Manchester symbol), where the slicer has no third sampling phase to spare for a carrier offset."""
+    return {512: 13.0e3, 768: 15.0e3}[int(D)]
+
+
 def design_taps(P, M=1024, cutoff_hz=13.0e3, chan_hz=30.0e3, beta=8.0):
     """Kaiser(beta) windowed sinc with unit DC gain: the prototype specified in DESIGN.md."""
     L = P * M
@@ -20,7 +26,7 @@ def design_taps(P, M=1024, cutoff_hz=13.0e3, chan_hz=30.0e3, beta=8.0):
 
 def channelize(x, P=8, M=1024, D=512, first_bin=0, n_channels=None, taps=None):
     """x: complex wideband stream from sample 0.  Returns complex128 [C][nframes], nframes = len(x) // D."""
-    h = design_taps(P, M) if taps is None else np.asarray(taps, np.float64)
+    h = design_taps(P, M, cutoff_for_decim(D)) if taps is None else np.asarray(taps, np.float64)
     L = h.size
     x = np.asarray(x, np.complex128)
     nfr = x.size // D

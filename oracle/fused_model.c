@@ -134,6 +134,33 @@ static void capture(orc_fused_t *f, uint64_t nc, amps_recc_burst_t *out)
     int dly = 0, k0 = -(AMPS_RECC_TRIGGER_SYMS / 2);          /* bit index relative to the capture: the trigger is bits -37 .. -1 */
     for (int b = 0; b < AMPS_TRACK_BLOCKS; b++) {
         const int nb = b == 0 ? AMPS_RECC_TRIGGER_SYMS / 2 : b == 1 ? 7 + AMPS_RECC_WORD_BITS : AMPS_RECC_WORD_BITS;
+        if (sps == 2) {
+            /* Two samples per symbol (the wideband seam at D = 768): ONE slicer bit lies between the two instants of a pair, which
+             * says which side of it the transition was on but not how far -- no first-order loop can be steered by that.  What the
+             * hard bits do carry is the number of Manchester violations (pairs a == b): the block is taken at whichever of the delays
+             * d - 1, d, d + 1 (d = the block before; 0 in front of the trigger) shows the fewest of them in THIS block, d on a
+             * tie, then d - 1.  (The other sample phase one symbol early or late pairs symbols across bit boundaries and violates in
+             * every second bit, so at most one neighbour is ever a candidate.)  The block that decides is the block that is taken:
+             * the first repeat of word A -- which the reference parses uncorrected -- is already sampled at the better phase. */
+            if (f->track) {
+                int v[3] = { 0, 0, 0 };
+                for (int c = 0; c < 3; c++)
+                    for (int k = k0; k < k0 + nb; k++) {
+                        const int64_t ta = (int64_t)nc + (int64_t)sps * (2 * k + 1) + dly + c - 1;
+                        v[c] += gbit(f, ta) == gbit(f, ta + sps);
+                    }
+                int best = 1;
+                if (v[0] < v[1]) best = 0;
+                if (v[2] < v[1] && v[2] < v[best]) best = 2;
+                dly += best - 1;
+            }
+            for (int k = k0 < 0 ? 0 : k0; k < k0 + nb; k++) {
+                const int64_t ta = (int64_t)nc + (int64_t)sps * (2 * k + 1) + dly;
+                burst[2 * k] = (uint8_t)gbit(f, ta); burst[2 * k + 1] = (uint8_t)gbit(f, ta + sps);
+            }
+            k0 += nb;
+            continue;
+        }
         int E[2] = { 0, 0 }, n[2] = { 0, 0 };
         for (int k = k0; k < k0 + nb; k++) {
             /* (samples in front of the stream read 1, as they do in the trigger test: only a TOLERANT match can begin there -- the

@@ -18,8 +18,8 @@ def test_trigger_is_the_last_37_preamble_bits():
     assert trackref.trigger_symbols().tolist() == list(oracle.trigger())
 
 
-def _run(case, seed):
-    rng, info, iq = fuzzlib.build_case(case, seed)
+def _run(case, seed, sps=None):
+    rng, info, iq = fuzzlib.build_case(case, seed, sps)
     sps, tol, track = info["sps"], info["tol"], not info["fixed"]
     nb = 0
     for c in range(iq.shape[0]):
@@ -51,6 +51,45 @@ def test_model_equals_the_second_statement_on_random_streams():
     assert {s for s, *_ in seen} == {0, 1, 2, 3}                   # every slicer spec's bits went through both statements
     assert any(fx for _, fx, *_ in seen) and any(not fx for _, fx, *_ in seen)
     assert any(t for *_, t, _, _ in seen) and any(p for *_, p, _ in seen) and any(cf for *_, cf in seen)
+
+
+def test_two_samples_per_symbol_rule_in_both_statements():
+    """the wideband seam at D = 768 delivers two samples per symbol, where a block picks its own delay by its Manchester violations
+    (DESIGN.md 4.4b): the same random streams, forced to that rate, through both statements"""
+    total, moved = 0, 0
+    for case in range(60):
+        nb, info = _run(case, 777, sps=2)
+        total += nb
+    assert total >= 70
+
+
+def test_two_samples_per_symbol_follows_a_clock_offset():
+    """a burst 500 ppm slow slides 3.5 samples through a capture at two samples per symbol.  The stream is made the way the wideband
+    seam sees it -- modulated at 480 ksps, through the filter bank's prototype (decimated to that rate), every twelfth sample -- so the
+    slide is smooth, not one whole sample at a time.  Tracked, every transmitted word arrives; at one fixed phase the late words do
+    not; and both statements agree on every symbol."""
+    from gr_amps_amd import synth
+    from oracle import channelizer as cz
+    rng = np.random.default_rng(11)
+    _, min10, _, _, words = synth.random_message(rng)
+    bits = synth.burst_bits(words, dcc=1, rng=rng)
+    x = synth.fsk_modulate(24 * (1000 + 2 * len(bits) + 1500), [(24 * 700 + 5, bits)], sps=24, fs=480e3, snr_db=14, rng=rng,
+                           dtype=np.complex128, sym_ppm=-500.0)
+    h = cz.design_taps(8, cutoff_hz=cz.cutoff_for_decim(768))[::64] * 64.0
+    iq = np.convolve(x, h)[:x.size][3::12].astype(np.complex64)
+    f = oracle.Fused(0, 2)
+    recs = f.push(iq, cap=8)
+    g = f.taps()[2]
+    (nc, sym), = trackref.captures(g, 2)
+    assert len(recs) == 1 and int(recs[0]["position"]) == nc and recs[0]["valid"].all()
+    want = refdecode.decode(sym)
+    _check(recs[0], want, 0)
+    assert want["min"] == min10
+    sent = [list(w) for w in words]
+    assert [list(recs[0]["word_dec"][w]) for w in range(len(sent))] == sent
+    fixed = oracle.decode_bursts(trackref.capture(g, nc, 2, track=False))[0]
+    nw = len(sent)
+    assert [list(fixed["word_dec"][w]) for w in range(nw)] != sent or not fixed["valid"][:nw].all()
 
 
 def test_tracking_moves_and_both_statements_move_alike():

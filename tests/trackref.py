@@ -70,18 +70,25 @@ def _bit(g, n):
 def capture(g, nc, sps, track=True):
     """Symbol i of the capture = slicer bit n_c + sps (i + 1) + delay; the delay starts at 0 and may change by one sample after each of
     36 blocks of bits: the trigger's own 37 bits (in front of the capture: measured, not kept), the 7 bits of the coded DCC together
-    with the first 48-bit repeat, then the other 34 repeats."""
+    with the first 48-bit repeat, then the other 34 repeats.  From three samples per symbol on, a block's mid-bit transitions move everything
+    BEHIND it; at two samples per symbol a block chooses its OWN delay by its Manchester violations."""
     sizes = [TRIGGER_SYMS // 2, 7 + WORD_BITS] + [WORD_BITS] * (WORDS * REPEATS - 1)
     assert len(sizes) == TRACK_BLOCKS and sum(sizes[1:]) * 2 == CAPTURE_SYMS
     sym = np.zeros(CAPTURE_SYMS, np.uint8)
     delay, first = 0, -(TRIGGER_SYMS // 2)
     for nb in sizes:
         k = np.arange(first, first + nb)
+        if track and sps == 2:
+            # two samples per symbol: the block is taken at whichever of the previous block's delay and its two neighbours shows the
+            # fewest Manchester violations (both symbols of a bit equal) in this very block; the old delay wins a tie, then the earlier
+            t3 = nc + sps * (2 * k[None, :] + 1) + delay + np.array([0, -1, 1])[:, None]
+            viol = (_bit(g, t3) == _bit(g, t3 + sps)).sum(1)
+            delay += (0, -1, 1)[int(np.argmin(viol))]                       # argmin returns the FIRST minimum: order (d, d - 1, d + 1)
         t = nc + sps * (2 * k + 1) + delay                                  # first sampling instant of bit k; the second is one symbol on
         a, b = _bit(g, t), _bit(g, t + sps)
         keep = k >= 0
         sym[2 * k[keep]], sym[2 * k[keep] + 1] = a[keep], b[keep]
-        if track:
+        if track and sps > 2:
             between = _bit(g, t[:, None] + np.arange(1, sps)[None, :])      # the sps - 1 slicer bits between the two instants
             late = (between == a[:, None]).sum(1) - Fraction(sps - 1, 2)    # bits still equal to a: how late the mid-bit transition came
             pair = a != b                                                   # only a valid Manchester pair has a transition to measure
