@@ -415,13 +415,22 @@ static void launch_resolve(amps_recc *h, ResolveArgs &ra, hipStream_t s)
     // that a change to either threshold cannot turn into a launch failure: a handle without a queue stays on the narrow kernel, whose
     // batches walk any number of segments.
     const bool wide = ra.tiles_per_channel / ra.span + 2 > (uint64_t)RESOLVE_THREADS && h->capq != nullptr;
-    if (wide)
-        hipLaunchKernelGGL((recc_resolve_kernel<RESOLVE_THREADS_WIDE, RESOLVE_LDS_HITS_WIDE>), dim3(h->C), dim3(RESOLVE_THREADS_WIDE), lds, s, ra);
-    else
-        hipLaunchKernelGGL((recc_resolve_kernel<RESOLVE_THREADS, RESOLVE_LDS_HITS>), dim3(h->C), dim3(RESOLVE_THREADS), lds, s, ra);
-    if (h->capq)
-        hipLaunchKernelGGL(recc_capture_kernel, dim3(std::min<uint32_t>(h->cfg.max_bursts, 2048u)), dim3(64),
-                           (size_t)resolve_cap_stride(ra.cap_words) * 8, s, ra);
+    // two samples per symbol (the wideband seam at D = 768) have their own capture rule: a second instantiation of the kernels, so that
+    // the default ones carry nothing of it
+    const bool two = h->sps == 2;
+    if (wide) {
+        if (two) hipLaunchKernelGGL((recc_resolve_kernel<RESOLVE_THREADS_WIDE, RESOLVE_LDS_HITS_WIDE, true>), dim3(h->C), dim3(RESOLVE_THREADS_WIDE), lds, s, ra);
+        else hipLaunchKernelGGL((recc_resolve_kernel<RESOLVE_THREADS_WIDE, RESOLVE_LDS_HITS_WIDE, false>), dim3(h->C), dim3(RESOLVE_THREADS_WIDE), lds, s, ra);
+    } else {
+        if (two) hipLaunchKernelGGL((recc_resolve_kernel<RESOLVE_THREADS, RESOLVE_LDS_HITS, true>), dim3(h->C), dim3(RESOLVE_THREADS), lds, s, ra);
+        else hipLaunchKernelGGL((recc_resolve_kernel<RESOLVE_THREADS, RESOLVE_LDS_HITS, false>), dim3(h->C), dim3(RESOLVE_THREADS), lds, s, ra);
+    }
+    if (h->capq) {
+        const dim3 gq(std::min<uint32_t>(h->cfg.max_bursts, 2048u));
+        const size_t ldsq = (size_t)resolve_cap_stride(ra.cap_words) * 8;
+        if (two) hipLaunchKernelGGL(recc_capture_kernel<true>, gq, dim3(64), ldsq, s, ra);
+        else hipLaunchKernelGGL(recc_capture_kernel<false>, gq, dim3(64), ldsq, s, ra);
+    }
 #ifdef RESOLVE_TIMELINE
     if (const char *path = std::getenv("AMPS_RECC_RESOLVE_TIMELINE")) {   // the last launch's stamps, raw
         std::vector<unsigned long long> tl((size_t)24 * h->C);
@@ -524,10 +533,13 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
     *out = nullptr;
     if (cfg->struct_size != sizeof(amps_recc_cfg_t)) return -EINVAL;
     if (cfg->n_channels < 1 || cfg->max_bursts < 1) return -EINVAL;
-    if (cfg->max_samples_per_push && !sps_supported(cfg->samples_per_symbol)) return -EINVAL;
-    // the channelizer's geometry (M = 1024, D = 512 at 30.72 Msps) delivers 60 ksps = 3 samples per Manchester symbol, and the
-    // bit-domain kernels behind it are built for exactly that
-    if (cfg->wideband_channels && (cfg->samples_per_symbol != 3 || cfg->max_samples_per_push == 0)) return -EINVAL;
+    // the channelizer's geometry (M = 1024 at 30.72 Msps) delivers 60 ksps = 3 samples per Manchester symbol at D = 512 and 40 ksps =
+    // 2 at D = 768; the bit-domain kernels behind it are built for exactly those.  Two samples per symbol exist on the wideband seam only
+    // (the streaming kernel of the IQ seam has no such instantiation).
+    const bool wide768 = cfg->wideband_channels && cfg->wideband_decim == (uint32_t)CHZ_D768;
+    if (cfg->max_samples_per_push && !(wide768 ? cfg->samples_per_symbol == 2 : sps_supported(cfg->samples_per_symbol))) return -EINVAL;
+    if (cfg->wideband_channels && (cfg->samples_per_symbol != (wide768 ? 2u : 3u) || cfg->max_samples_per_push == 0)) return -EINVAL;
+    if (wide768 && bits_kernel_is_front()) return -EINVAL;        // AMPS_RECC_BITS_KERNEL=front: the streaming kernel's bit-domain mode is built for 3 samples per symbol
     if (cfg->sync_tolerance > AMPS_RECC_MAX_SYNC_TOLERANCE) return -EINVAL;
     {
         const uint32_t sl = cfg->flags & (AMPS_RECC_FLAG_SLICER_PRODUCT | AMPS_RECC_FLAG_SLICER_SINE | AMPS_RECC_FLAG_SLICER_ATAN | AMPS_RECC_FLAG_SLICER_EXACT);
@@ -614,6 +626,9 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
             if (bits_kernel_is_front())
                 e = cfg->sync_tolerance ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, recc_front_kernel<3, 1, true, true>, 256, 0)
                                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, recc_front_kernel<3, 1, true, false>, 256, 0);
+            else if (h->sps == 2)
+                e = cfg->sync_tolerance ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, recc_bits_kernel<2, true>, 256, 0)
+                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, recc_bits_kernel<2, false>, 256, 0);
             else
                 e = cfg->sync_tolerance ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, recc_bits_kernel<3, true>, 256, 0)
                                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, recc_bits_kernel<3, false>, 256, 0);
@@ -830,6 +845,9 @@ int run_bits_device(amps_recc *h, uint32_t P)
         if (bits_kernel_is_front()) {
             if (fa.tol) hipLaunchKernelGGL((recc_front_kernel<3, 1, true, true>), grid, dim3(256), 0, s, fa);
             else hipLaunchKernelGGL((recc_front_kernel<3, 1, true>), grid, dim3(256), 0, s, fa);
+        } else if (h->sps == 2) {
+            if (fa.tol) hipLaunchKernelGGL((recc_bits_kernel<2, true>), grid, dim3(256), 0, s, fa);
+            else hipLaunchKernelGGL((recc_bits_kernel<2, false>), grid, dim3(256), 0, s, fa);
         } else if (fa.tol) hipLaunchKernelGGL((recc_bits_kernel<3, true>), grid, dim3(256), 0, s, fa);
         else hipLaunchKernelGGL((recc_bits_kernel<3, false>), grid, dim3(256), 0, s, fa);
     }
@@ -900,7 +918,7 @@ int amps_recc_rccl_init(amps_recc_t *h, const uint8_t *id, int nranks, int rank)
     loc.groups = h->cfg.wideband_groups >= 2 ? h->cfg.wideband_groups : 0;
     loc.group = h->cfg.wideband_group;
     // the largest block one push takes: max_samples_per_push frames of 512 samples (amps_recc_push_wideband: -E2BIG beyond)
-    loc.cap_samples = (uint64_t)h->cfg.max_samples_per_push * CHZ_D;
+    loc.cap_samples = (uint64_t)h->cfg.max_samples_per_push * (uint64_t)h->chz.D;
     loc.max_bursts = h->cfg.max_bursts;
     const int rc = rccl_init(h->rccl, id, nranks, rank, loc, sizeof(amps_recc_burst_t));
     if (rc == 0) h->rccl.timing = h->timing;
@@ -1237,12 +1255,14 @@ int amps_recc_debug_exact_slice(int form, int sps, const uint32_t *in, uint32_t 
 {
     if (!in || !out) return -EINVAL;
     if (form == 1) {
-        if (sps != 3) return -EINVAL;
-        out[0] = exact_slice_word3(in[0], in[1], in[2], in[3], in[4], in[5], out[1], out[2]);
+        if (sps == 3) out[0] = exact_slice_word3(in[0], in[1], in[2], in[3], in[4], in[5], out[1], out[2]);
+        else if (sps == 2) out[0] = exact_slice_word2(in[0], in[1], in[2], in[3], in[4], in[5], out[1], out[2]);
+        else return -EINVAL;
         return 0;
     }
     if (form != 0) return -EINVAL;
     switch (sps) {
+    case 2: out[0] = exact_slice_word<2>(in[0], in[1], in[2]); break;
     case 3: out[0] = exact_slice_word<3>(in[0], in[1], in[2]); break;
     case 4: out[0] = exact_slice_word<4>(in[0], in[1], in[2]); break;
     case 5: out[0] = exact_slice_word<5>(in[0], in[1], in[2]); break;

@@ -57,7 +57,8 @@ struct StageFence {
 };
 
 constexpr int CHZ_M = 1024;          // branches = FFT size
-constexpr int CHZ_D = 512;           // input samples per frame (2x oversampled)
+constexpr int CHZ_D = 512;           // input samples per frame of the default form (2x oversampled: 60 ksps per channel, 3 samples per symbol)
+constexpr int CHZ_D768 = 768;        // ... of the 4/3 x oversampled form (40 ksps per channel, 2 samples per symbol; round 6, section "D = 768" below)
 
 struct ChzArgs {
     const float2 *block;     // new wideband samples of this push
@@ -269,6 +270,17 @@ struct ChzIn {
         else { const int64_t bi = v - lead; if (bi >= nsamp) return (cf2){ 0.f, 0.f }; s = block[bi]; }
         return (cf2){ s.x, s.y };
     }
+    // the same without a branch around the load: the edge paths fetch a batch of these and wait ONCE (round 6: sixteen -- at D = 768
+    // nineteen -- generic loads of a workgroup's prologue each behind its own drain were that many HBM round trips in a row)
+    __device__ __forceinline__ cf2 generic_nb(int64_t v) const
+    {
+        const int64_t ci = v + hist, bi = v - lead;
+        const bool in_carry = ci < carry_len, ok = ci >= 0 && (in_carry || bi < nsamp);
+        const float2 *p = in_carry ? carry + ci : block + bi;
+        p = ok ? p : carry;                                           // any valid address
+        const float2 s = *p;
+        return ok ? (cf2){ s.x, s.y } : (cf2){ 0.f, 0.f };
+    }
     // all CHZ_BATCH frames starting at F lie inside the new block (wave-uniform)
     __device__ __forceinline__ bool batch_in_block(int64_t F) const
     {
@@ -408,9 +420,26 @@ __device__ __forceinline__ void chz_load1_ring(cf2 (&ring)[4][P + 4], const ChzI
         asm volatile("v_mov_b64 %0, %1" : "+v"(ring[J + 1][E]) : "v"(s1));
     }
 }
+// the eight generic loads of a half-step as ONE batch: all of them in flight, one drain, then into their slots through the same ties
+template <int P, int BASE, int ELEM>
+__device__ __forceinline__ void chz_load_half_ring_generic(cf2 (&ring)[4][P + 4], const ChzIn &in, int64_t F, int t)
+{
+    constexpr int R = P + 4;
+    cf2 v[8];
+#pragma unroll
+    for (int g = 0; g < 4; g++) { v[2 * g] = in.generic_nb((F + g) * CHZ_D + t); v[2 * g + 1] = in.generic_nb((F + g) * CHZ_D + 256 + t); }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) :: "memory");
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const int e = (BASE + ELEM + (g >> 1)) % R, j = 2 * (g & 1);
+        asm volatile("v_mov_b64 %0, %1" : "+v"(ring[j][e]) : "v"(v[2 * g]));
+        asm volatile("v_mov_b64 %0, %1" : "+v"(ring[j + 1][e]) : "v"(v[2 * g + 1]));
+    }
+}
 template <int P, int BASE, int ELEM, bool FAST>
 __device__ __forceinline__ void chz_load_half_ring(cf2 (&ring)[4][P + 4], const ChzIn &in, int64_t F, int t)
 {
+    if constexpr (!FAST) { chz_load_half_ring_generic<P, BASE, ELEM>(ring, in, F, t); return; }
     chz_load1_ring<P, BASE, ELEM, 0, FAST>(ring, in, F, t);
     chz_load1_ring<P, BASE, ELEM, 1, FAST>(ring, in, F, t);
     chz_load1_ring<P, BASE, ELEM, 2, FAST>(ring, in, F, t);
@@ -427,6 +456,152 @@ __device__ __forceinline__ void chz_ring_wait(cf2 (&ring)[4][P + 4])
                       "+v"(ring[0][(BASE + P + 1) % R]), "+v"(ring[1][(BASE + P + 1) % R]), "+v"(ring[2][(BASE + P + 1) % R]), "+v"(ring[3][(BASE + P + 1) % R]));
 }
 
+
+
+// ---- D = 768: the fold role of the 4/3 x oversampled bank (M = 1024, 40 ksps per channel = two samples per Manchester symbol) ----
+// Everything per FRAME is what it is at D = 512 -- eight taps on each of 1024 branches, the same FFT, the same slicer work per bin --
+// but a frame now consumes 768 input samples instead of 512: 1.5 x fewer frames per input byte (the D = 512 form ends at
+// 0.33 of HBM, bound by VALU issue).  What changes is the bookkeeping of the fold, all of it compile-time:
+//   * frame F (F = 0 mod 4 at the start of a half-step; launches and workgroup ranges start on multiples of four frames, where the
+//     stream position is a multiple of M) brings the chunks k = 0, 1, 2 of 256 samples; chunk k belongs to branch j = (k - g) & 3,
+//     g = F & 3: per half-step of four frames every branch receives THREE samples -- branch j in the frames g with (j + g) & 3 != 3;
+//   * branch j of frame g is weighted with coefficient set (j + g + 1) & 3 (the prototype is indexed by the sample's distance from
+//     the frame's start, (r - n0) mod M with n0 = (F + 1) D - L = 256 (g + 1) mod M) -- the same 32 coefficients per thread as at
+//     D = 512, where the set alternates between j and j ^ 2;
+//   * the register ring keeps P + 4 = 12 slots per branch, as at D = 512, and advances by three per half-step: period FOUR
+//     half-steps.  In the view of a half-step, elements 0..7 are the delay line, 8..10 its own three samples, 11 the first sample of
+//     the next one.  Frame g reads the window [cnt(j, g), cnt(j, g) + 8) of branch j, cnt = samples received so far; every element
+//     0..3 dies in the FIRST tap block of a frame pair (position 0 of its last window), and the slot takes a load at once:
+//        after the first tap block of frames 0 / 1:  element 0 of branch 3, element 1 of every branch, element 2 of branch 0
+//        after the first tap block of frames 2 / 3:  element 2 of branches 1..3, element 3 of branches 0..2
+//     The slot of element e receives element e + 12: the samples of the next half-step (9, 10 there) and of the one after (8, 9
+//     there), issued in the order they will be needed, so ONE counter serves: s_waitcnt vmcnt(13) in front of either frame pair
+//     leaves exactly the thirteen loads issued behind the last one that pair reads.  A load has five to seven frames to land
+//     (D = 512: four to eight), 13 x 512 B x 4 waves = 26 KB per CU are in flight at the least.
+__host__ __device__ constexpr int chz768_recv(int j, int g) { return ((j + g) & 3) != 3; }           // branch j receives a sample in frame g
+__host__ __device__ constexpr int chz768_cnt(int j, int g) { int c = 0; for (int q = 0; q <= g; q++) c += chz768_recv(j, q); return c; }
+static_assert(chz768_cnt(0, 0) == 1 && chz768_cnt(0, 3) == 3 && chz768_cnt(1, 2) == 2 && chz768_cnt(2, 1) == 1 && chz768_cnt(3, 0) == 0 && chz768_cnt(3, 3) == 3, "reception table");
+constexpr int CHZ768_R = 12;
+// frames FA, FA + 1 of a half-step (FA = 0 or 2), then the radix-4 pass 1 of both -> A[FA], A[FA + 1].  The asm block of
+// chz_fold_taps2 is the D = 512 one -- its first frame's accumulator jb uses coefficient pair c[jb ^ 2], its second frame's c[jb] --
+// handed permuted operands: c[m] = set (m + FA + 2) & 3, second frame = branch jb, first frame = branch (jb + 3) & 3 (all
+// indices compile-time: no register moves)
+template <int P, int BASE, int FA, typename Hook>
+__device__ __forceinline__ void chz768_fold2_ring(const cf2 (&ring)[4][CHZ768_R], const cf2 (&coef)[4][P / 2], const cf2 (&tw1)[3], cf2 *bufA, int t, Hook &&after_first)
+{
+    static_assert(P == 8 && (FA == 0 || FA == 2), "eight taps per branch, frame pairs 0 / 1 and 2 / 3");
+    constexpr int R = CHZ768_R;
+    cf2 acc[2][4];
+#pragma unroll
+    for (int q = 0; q < P; q += 2) {
+        cf2 x0[2][4], x1[2][4], c[4];
+#pragma unroll
+        for (int jb = 0; jb < 4; jb++) {
+            const int j0 = (jb + 3) & 3, s0 = chz768_cnt(j0, FA), s1 = chz768_cnt(jb, FA + 1);
+            x0[0][jb] = ring[j0][(BASE + s0 + q) % R]; x1[0][jb] = ring[j0][(BASE + s0 + q + 1) % R];
+            x0[1][jb] = ring[jb][(BASE + s1 + q) % R]; x1[1][jb] = ring[jb][(BASE + s1 + q + 1) % R];
+        }
+#pragma unroll
+        for (int m = 0; m < 4; m++) c[m] = coef[(m + FA + 2) & 3][q / 2];
+        if (q == 0) { chz_fold_taps2<true>(acc, x0, x1, c); after_first(); } else chz_fold_taps2<false>(acc, x0, x1, c);
+    }
+#pragma unroll
+    for (int f = 0; f < 2; f++) {
+        cf2 o[4];
+        if (f == 0) dft4(acc[0][1], acc[0][2], acc[0][3], acc[0][0], o);     // branch j of the first frame sits in accumulator (j + 1) & 3
+        else dft4(acc[1][0], acc[1][1], acc[1][2], acc[1][3], o);
+        cf2 *d = bufA + (FA + f) * CHZ_FB + t;
+        d[chz_pos1(0, 0)] = o[0]; d[chz_pos1(0, 1)] = cmul(o[1], tw1[0]); d[chz_pos1(0, 2)] = cmul(o[2], tw1[1]); d[chz_pos1(0, 3)] = cmul(o[3], tw1[2]);
+    }
+}
+// The sample branch J receives in frame G of the half-step X half-steps behind the one in work (whose first frame is F0, ring rotation
+// BASE): chunk K = (J + G) & 3 of that frame's 768 new samples, into the slot its reception number says.  FAST / generic as at
+// D = 512 (chz_load1_ring): untracked inline-asm loads tied to the slot's own registers, or a bounds-checked load drained at once.
+template <int BASE, int X, int G, int J, bool FAST>
+__device__ __forceinline__ void chz768_load1(cf2 (&ring)[4][CHZ768_R], const ChzIn &in, int64_t F0, int t)
+{
+    constexpr int K = (J + G) & 3;
+    static_assert(K != 3, "branch J receives nothing in frame G");
+    constexpr int SLOT = (BASE + 7 + chz768_cnt(J, G) + 3 * X) % CHZ768_R;
+    if constexpr (FAST) {
+        const uint32_t voff = (uint32_t)t * (uint32_t)sizeof(float2);
+        uint32_t f = (uint32_t)(F0 + 4 * X + G);                      // >= 0 on this path; clamped to the last whole frame of the block (see chz_load1_ring)
+        f = f < in.f_last ? f : in.f_last;
+        const float2 *q = in.block + ((int64_t)f * CHZ_D768 - in.lead) + 256 * K;
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(ring[J][SLOT]) : "v"(voff), "s"(q));
+    } else {
+        cf2 s0 = in.generic((F0 + 4 * X + G) * CHZ_D768 + 256 * K + t);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(s0) :: "memory");
+        asm volatile("v_mov_b64 %0, %1" : "+v"(ring[J][SLOT]) : "v"(s0));
+    }
+}
+// generic form in two halves, so that a batch of fetches shares one drain
+template <int X, int G, int J>
+__device__ __forceinline__ cf2 chz768_fetch(const ChzIn &in, int64_t F0, int t) { return in.generic_nb((F0 + 4 * X + G) * CHZ_D768 + 256 * ((J + G) & 3) + t); }
+template <int BASE, int X, int G, int J>
+__device__ __forceinline__ void chz768_put(cf2 (&ring)[4][CHZ768_R], cf2 v)
+{
+    constexpr int SLOT = (BASE + 7 + chz768_cnt(J, G) + 3 * X) % CHZ768_R;
+    asm volatile("v_mov_b64 %0, %1" : "+v"(ring[J][SLOT]) : "v"(v));
+}
+// the twelve loads of an EDGE half-step (both lists below), one drain
+template <int BASE>
+__device__ __forceinline__ void chz768_loads_generic(cf2 (&ring)[4][CHZ768_R], const ChzIn &in, int64_t F0, int t)
+{
+    cf2 v[12] = { chz768_fetch<1, 2, 3>(in, F0, t), chz768_fetch<1, 2, 0>(in, F0, t), chz768_fetch<1, 3, 1>(in, F0, t), chz768_fetch<1, 3, 2>(in, F0, t),
+                  chz768_fetch<1, 3, 3>(in, F0, t), chz768_fetch<2, 0, 0>(in, F0, t), chz768_fetch<2, 0, 1>(in, F0, t), chz768_fetch<2, 0, 2>(in, F0, t),
+                  chz768_fetch<2, 1, 3>(in, F0, t), chz768_fetch<2, 1, 0>(in, F0, t), chz768_fetch<2, 1, 1>(in, F0, t), chz768_fetch<2, 2, 2>(in, F0, t) };
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]) :: "memory");
+    chz768_put<BASE, 1, 2, 3>(ring, v[0]); chz768_put<BASE, 1, 2, 0>(ring, v[1]); chz768_put<BASE, 1, 3, 1>(ring, v[2]); chz768_put<BASE, 1, 3, 2>(ring, v[3]);
+    chz768_put<BASE, 1, 3, 3>(ring, v[4]); chz768_put<BASE, 2, 0, 0>(ring, v[5]); chz768_put<BASE, 2, 0, 1>(ring, v[6]); chz768_put<BASE, 2, 0, 2>(ring, v[7]);
+    chz768_put<BASE, 2, 1, 3>(ring, v[8]); chz768_put<BASE, 2, 1, 0>(ring, v[9]); chz768_put<BASE, 2, 1, 1>(ring, v[10]); chz768_put<BASE, 2, 2, 2>(ring, v[11]);
+}
+// what the half-steps -2 and -1 would have left in flight when half-step 0 (first frame F0, BASE 0) begins: its own three samples per
+// branch (slots 8..10), the first of half-step 1 (slot 11) and -- branches 0..2, whose element 0 is dead already -- the second (slot 0)
+__device__ __forceinline__ void chz768_prime(cf2 (&ring)[4][CHZ768_R], const ChzIn &in, int64_t F0, int t)
+{
+    cf2 a[12] = { chz768_fetch<0, 0, 0>(in, F0, t), chz768_fetch<0, 0, 1>(in, F0, t), chz768_fetch<0, 0, 2>(in, F0, t), chz768_fetch<0, 1, 3>(in, F0, t),
+                  chz768_fetch<0, 1, 0>(in, F0, t), chz768_fetch<0, 1, 1>(in, F0, t), chz768_fetch<0, 2, 2>(in, F0, t), chz768_fetch<0, 2, 3>(in, F0, t),
+                  chz768_fetch<0, 2, 0>(in, F0, t), chz768_fetch<0, 3, 1>(in, F0, t), chz768_fetch<0, 3, 2>(in, F0, t), chz768_fetch<0, 3, 3>(in, F0, t) };
+    cf2 b[7] = { chz768_fetch<1, 0, 0>(in, F0, t), chz768_fetch<1, 0, 1>(in, F0, t), chz768_fetch<1, 0, 2>(in, F0, t), chz768_fetch<1, 1, 3>(in, F0, t),
+                 chz768_fetch<1, 1, 0>(in, F0, t), chz768_fetch<1, 1, 1>(in, F0, t), chz768_fetch<1, 2, 2>(in, F0, t) };
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]) :: "memory");
+    asm volatile("" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]));
+    chz768_put<0, 0, 0, 0>(ring, a[0]); chz768_put<0, 0, 0, 1>(ring, a[1]); chz768_put<0, 0, 0, 2>(ring, a[2]); chz768_put<0, 0, 1, 3>(ring, a[3]);
+    chz768_put<0, 0, 1, 0>(ring, a[4]); chz768_put<0, 0, 1, 1>(ring, a[5]); chz768_put<0, 0, 2, 2>(ring, a[6]); chz768_put<0, 0, 2, 3>(ring, a[7]);
+    chz768_put<0, 0, 2, 0>(ring, a[8]); chz768_put<0, 0, 3, 1>(ring, a[9]); chz768_put<0, 0, 3, 2>(ring, a[10]); chz768_put<0, 0, 3, 3>(ring, a[11]);
+    chz768_put<0, 1, 0, 0>(ring, b[0]); chz768_put<0, 1, 0, 1>(ring, b[1]); chz768_put<0, 1, 0, 2>(ring, b[2]); chz768_put<0, 1, 1, 3>(ring, b[3]);
+    chz768_put<0, 1, 1, 0>(ring, b[4]); chz768_put<0, 1, 1, 1>(ring, b[5]); chz768_put<0, 1, 2, 2>(ring, b[6]);
+}
+// the six loads behind the first tap block of frames 0 / 1, and the six behind that of frames 2 / 3, in the order they are needed
+template <int BASE, bool FAST>
+__device__ __forceinline__ void chz768_loads_a(cf2 (&ring)[4][CHZ768_R], const ChzIn &in, int64_t F0, int t)
+{
+    chz768_load1<BASE, 1, 2, 3, FAST>(ring, in, F0, t); chz768_load1<BASE, 1, 2, 0, FAST>(ring, in, F0, t);
+    chz768_load1<BASE, 1, 3, 1, FAST>(ring, in, F0, t); chz768_load1<BASE, 1, 3, 2, FAST>(ring, in, F0, t);
+    chz768_load1<BASE, 1, 3, 3, FAST>(ring, in, F0, t); chz768_load1<BASE, 2, 0, 0, FAST>(ring, in, F0, t);
+}
+template <int BASE, bool FAST>
+__device__ __forceinline__ void chz768_loads_b(cf2 (&ring)[4][CHZ768_R], const ChzIn &in, int64_t F0, int t)
+{
+    chz768_load1<BASE, 2, 0, 1, FAST>(ring, in, F0, t); chz768_load1<BASE, 2, 0, 2, FAST>(ring, in, F0, t);
+    chz768_load1<BASE, 2, 1, 3, FAST>(ring, in, F0, t); chz768_load1<BASE, 2, 1, 0, FAST>(ring, in, F0, t);
+    chz768_load1<BASE, 2, 1, 1, FAST>(ring, in, F0, t); chz768_load1<BASE, 2, 2, 2, FAST>(ring, in, F0, t);
+}
+// in front of frames 0 / 1: element 8 of every branch and element 9 of branches 0, 1 have arrived (everything but the thirteen
+// youngest loads); in front of frames 2 / 3: element 9 of branches 2, 3 and element 10 of every branch (again thirteen)
+template <int BASE, int FA>
+__device__ __forceinline__ void chz768_ring_wait(cf2 (&ring)[4][CHZ768_R])
+{
+    constexpr int R = CHZ768_R;
+    asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+    if constexpr (FA == 0)
+        asm volatile("" : "+v"(ring[0][(BASE + 8) % R]), "+v"(ring[1][(BASE + 8) % R]), "+v"(ring[2][(BASE + 8) % R]), "+v"(ring[3][(BASE + 8) % R]),
+                          "+v"(ring[0][(BASE + 9) % R]), "+v"(ring[1][(BASE + 9) % R]));
+    else
+        asm volatile("" : "+v"(ring[2][(BASE + 9) % R]), "+v"(ring[3][(BASE + 9) % R]),
+                          "+v"(ring[0][(BASE + 10) % R]), "+v"(ring[1][(BASE + 10) % R]), "+v"(ring[2][(BASE + 10) % R]), "+v"(ring[3][(BASE + 10) % R]));
+}
 
 // ---- the three-role pipeline ----
 // Round 2's kernel had two roles (4 fold waves, 8 FFT waves that also ran the slicer): the eight FFT waves moved in lock step
@@ -450,7 +625,10 @@ constexpr int CHZ12_IQ = -1;                                     // MODE: write 
 
 // Slicer state of TWO channels of one lane, planar (.x = the first channel, .y = the second): the specs of
 // include/amps_recc_numerics.h, operation by operation, two channels per packed instruction.
-template <int SL> struct ChzSlicePair {
+// SPS = frames per Manchester symbol: 3 behind the D = 512 bank, 2 behind the D = 768 one (the partner of specs B / D is SPS frames
+// back, the boxcar of specs A / C is SPS long -- at SPS = 2 its ordered sum is d[n-1] + d[n] whatever the parity)
+template <int SL, int SPS = 3> struct ChzSlicePair {
+    static_assert(SPS == 2 || SPS == 3, "frames per symbol");
     f2 pr, pi;               // spec A / C: the bins one frame earlier
     f2 d1, d2;               // spec A / C: the last two discriminator outputs
     f2 h1r, h1i, h2r, h2i, h3r, h3i;   // spec B: the bins one, two and three frames earlier
@@ -470,7 +648,8 @@ template <int SL> struct ChzSlicePair {
     __device__ __forceinline__ uint32_t exact_word(int e)
     {
         uint32_t wp, wm;
-        const uint32_t g = exact_slice_word3(sx[e], st[e], gw[e], sxp[e], wpp[e], wmp[e], wp, wm);   // recc_front.hip.h
+        const uint32_t g = SPS == 3 ? exact_slice_word3(sx[e], st[e], gw[e], sxp[e], wpp[e], wmp[e], wp, wm)    // recc_front.hip.h
+                                    : exact_slice_word2(sx[e], st[e], gw[e], sxp[e], wpp[e], wmp[e], wp, wm);
         sxp[e] = sx[e]; wpp[e] = wp; wmp[e] = wm;
         return g;
     }
@@ -478,7 +657,8 @@ template <int SL> struct ChzSlicePair {
     {
         if constexpr (SL == AMPS_SLICER_EXACT) {
             const f2 it = __builtin_elementwise_fma(yi, pr, -(yr * pi));       // Im(y conj(y[n-1]))
-            const f2 ic = __builtin_elementwise_fma(yi, h3r, -(yr * h3i));     // Im(y conj(y[n-3]))
+            const f2 qr = SPS == 3 ? h3r : h2r, qi = SPS == 3 ? h3i : h2i;
+            const f2 ic = __builtin_elementwise_fma(yi, qr, -(yr * qi));       // Im(y conj(y[n-SPS]))
             sx[0] = __builtin_amdgcn_alignbit(sx[0], __float_as_uint(yi.x), 31);
             sx[1] = __builtin_amdgcn_alignbit(sx[1], __float_as_uint(yi.y), 31);
             st[0] = __builtin_amdgcn_alignbit(st[0], __float_as_uint(it.x), 31);
@@ -487,8 +667,8 @@ template <int SL> struct ChzSlicePair {
             gw[1] = __builtin_amdgcn_alignbit(gw[1], __float_as_uint(ic.y), 31);
             h3r = h2r; h3i = h2i; h2r = pr; h2i = pi; pr = yr; pi = yi;
         } else if constexpr (SL == AMPS_SLICER_PRODUCT) {
-            // g = !signbit(yi * pr3 - yr * pi3), the partner three frames (one Manchester symbol) earlier
-            const f2 sd = yi * h3r - yr * h3i;
+            // g = !signbit(yi * pr3 - yr * pi3), the partner SPS frames (one Manchester symbol) earlier
+            const f2 sd = SPS == 3 ? yi * h3r - yr * h3i : yi * h2r - yr * h2i;
             gw[0] = __builtin_amdgcn_alignbit(gw[0], __float_as_uint(sd.x), 31);
             gw[1] = __builtin_amdgcn_alignbit(gw[1], __float_as_uint(sd.y), 31);
             h3r = h2r; h3i = h2i; h2r = h1r; h2i = h1i; h1r = yr; h1i = yi;
@@ -501,7 +681,7 @@ template <int SL> struct ChzSlicePair {
                 d = fm_phase_planar(re, im);
             }
             // window [n-2, n]: n even -> (d[n-2] + d[n-1]) + d[n];  n odd -> d[n-2] + (d[n-1] + d[n])
-            const f2 s = PAR == 0 ? (d2 + d1) + d : d2 + (d1 + d);
+            const f2 s = SPS == 2 ? d1 + d : PAR == 0 ? (d2 + d1) + d : d2 + (d1 + d);
             const f2 sp = SL == AMPS_SLICER_SINE ? s : s + (f2){ 0.0f, 0.0f };   // spec A: g = (S >= 0), i.e. -0 counts as +0 (see step4)
             gw[0] = __builtin_amdgcn_alignbit(gw[0], __float_as_uint(sp.x), 31);
             gw[1] = __builtin_amdgcn_alignbit(gw[1], __float_as_uint(sp.y), 31);
@@ -524,7 +704,7 @@ template <int SL> struct ChzSlicePair {
             fm_phase_planar_n<4>(re, im, d);
 #pragma unroll
             for (int g = 0; g < 4; g++) {
-                const f2 s = (g & 1) == 0 ? (d2 + d1) + d[g] : d2 + (d1 + d[g]);
+                const f2 s = SPS == 2 ? d1 + d[g] : (g & 1) == 0 ? (d2 + d1) + d[g] : d2 + (d1 + d[g]);
                 // g = (S >= 0): S + (+0) turns the one negative-signed value that counts as >= 0, -0, into +0 (and leaves every
                 // other finite S alone), after which the bit is the inverted sign -- one packed add and two funnel shifts for
                 // the pair instead of two compares, two selects and two shifts
@@ -549,9 +729,9 @@ template <int SL> struct ChzSlicePair {
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             const f2 p1r = g >= 1 ? yr[g - 1] : hr[0], p1i = g >= 1 ? yi[g - 1] : hi[0];
-            const f2 p3r = g >= 3 ? yr[g - 3] : hr[2 - g], p3i = g >= 3 ? yi[g - 3] : hi[2 - g];
+            const f2 p3r = g >= SPS ? yr[g - SPS] : hr[SPS - 1 - g], p3i = g >= SPS ? yi[g - SPS] : hi[SPS - 1 - g];
             const f2 it = __builtin_elementwise_fma(yi[g], p1r, -(yr[g] * p1i));       // Im(y conj(y[n-1]))
-            const f2 ic = __builtin_elementwise_fma(yi[g], p3r, -(yr[g] * p3i));       // Im(y conj(y[n-3]))
+            const f2 ic = __builtin_elementwise_fma(yi[g], p3r, -(yr[g] * p3i));       // Im(y conj(y[n-SPS]))
             sx[0] = __builtin_amdgcn_alignbit(sx[0], __float_as_uint(yi[g].x), 31);
             sx[1] = __builtin_amdgcn_alignbit(sx[1], __float_as_uint(yi[g].y), 31);
             st[0] = __builtin_amdgcn_alignbit(st[0], __float_as_uint(it.x), 31);
@@ -575,9 +755,9 @@ template <int SL> struct ChzSlicePair {
 // block belonging to this handle (64 = all of them) a frame holds 8 W pairs, numbered vp = W * block + i'; pair j of (wave wf, lane)
 // is vp = 64 (4 (J0 + j) + wf) + lane.  W = 64: pair j holds bins 512 j + 128 wf + lane and + 64, consecutive lanes read consecutive
 // floats.  A pair-wave none of whose bins is decoded by this handle is skipped (wave-uniform).
-template <int SL, bool IQ> struct ChzSlicer {
+template <int SL, bool IQ, int SPS = 3> struct ChzSlicer {
     static constexpr int NB = CHZ_BATCH, M = CHZ_M, J0 = 0, NP = 2;   // channel pairs of a lane
-    ChzSlicePair<SL> S[NP];
+    ChzSlicePair<SL, SPS> S[NP];
     uint32_t ch[NP][2];                                           // row of the bin (>= n_channels: not decoded by this handle)
     uint32_t pbase[NP];                                           // float offset of the pair's first real part in a planar frame
     bool pair_on[NP];
@@ -706,7 +886,7 @@ template <int SL, bool IQ> struct ChzSlicer {
 #pragma unroll
                     for (int e = 0; e < 2; e++) {
                         uint32_t word = S[j].word(e);
-                        if ((SL == AMPS_SLICER_PRODUCT || SL == AMPS_SLICER_EXACT) && a.stream_start && F + NB - 1 == 31) word |= 7u;   // no partner yet: g = 1
+                        if ((SL == AMPS_SLICER_PRODUCT || SL == AMPS_SLICER_EXACT) && a.stream_start && F + NB - 1 == 31) word |= (1u << SPS) - 1u;   // no partner yet: g = 1
                         hold[j][e][0] = hold[j][e][1]; hold[j][e][1] = hold[j][e][2]; hold[j][e][2] = hold[j][e][3]; hold[j][e][3] = word;
                     }
                 nheld++;
@@ -771,10 +951,12 @@ __global__ __launch_bounds__(256) void chz_carry_kernel(const float2 *block, con
         carry_out[k] = chz_carry_sample(block, carry_in, carry_len, nsamp, hist, consumed, k);
 }
 
-template <int P, int MODE>
+template <int P, int MODE, int DEC = CHZ_D>
 __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
 {
-    constexpr int M = CHZ_M, D = CHZ_D, NB = CHZ_BATCH;
+    static_assert(DEC == CHZ_D || DEC == CHZ_D768, "input samples per frame");
+    constexpr int M = CHZ_M, D = DEC, NB = CHZ_BATCH;
+    constexpr int SPS = 1536 / DEC;                                   // frames per Manchester symbol (20 ksym/s at 30.72 Msps)
     constexpr bool IQ = MODE == CHZ12_IQ;
     constexpr int SL = IQ ? AMPS_SLICER_ATAN_BOXCAR : MODE;
     __shared__ cf2 buf[CHZ_SLOTS * NB * CHZ_FB];
@@ -831,7 +1013,7 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
         // ------------------------------------------------------------------ fold role
         const int t = tid & 255;
         const int64_t lead0 = (int64_t)a.carry_len - (int64_t)a.hist;
-        const int64_t fl = ((int64_t)a.nsamp - CHZ_D + lead0) / CHZ_D;      // floor for the non-negative values the FAST path sees
+        const int64_t fl = ((int64_t)a.nsamp - D + lead0) / D;              // floor for the non-negative values the FAST path sees
         const ChzIn in{ a.block, a.carry, (int64_t)a.hist, lead0, (int64_t)a.carry_len, (int64_t)a.nsamp, (uint32_t)(fl < 0 ? 0 : fl) };
         cf2 coef[4][P / 2];
 #pragma unroll
@@ -841,6 +1023,73 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
         cf2 tw1[3];                                               // pass 2's input twiddles of this thread's outputs k1 = 1..3
 #pragma unroll
         for (int k1 = 1; k1 < 4; k1++) tw1[k1 - 1] = chz_twiddle((t >> 4) * k1, 64);
+        if constexpr (DEC == CHZ_D768) {
+        // ---- D = 768 (section "D = 768" above): twelve ring slots per branch, three new samples per branch and half-step
+        cf2 ring[4][CHZ768_R];
+        {
+            const int64_t vend = fs * D;                          // multiple of M (fs is a multiple of four)
+#pragma unroll
+            for (int jb = 0; jb < 4; jb++) {
+                const int64_t vlast = vend - M + (t + 256 * jb);
+#pragma unroll
+                for (int q = 0; q < P; q++) ring[jb][q] = in.generic_nb(vlast - (int64_t)M * (P - 1 - q));
+            }
+        }
+        chz768_prime(ring, in, fs, t);
+        __syncthreads();                                          // all roles start together
+        auto half_step = [&](auto basec, auto edgec, int h) {
+            constexpr int BASE = decltype(basec)::value;
+            constexpr bool EDGE = decltype(edgec)::value;
+            CHZ_STAMP(h, 0);
+            if (__builtin_expect(h < nh, 1)) {
+                const int64_t F = fs + (int64_t)NB * h;
+                cf2 *dst = buf + (h & (CHZ_SLOTS - 1)) * NB * CHZ_FB;
+                chz768_ring_wait<BASE, 0>(ring);
+                CHZ_STAMP(h, 1);
+                if constexpr (EDGE) {
+                    chz768_fold2_ring<P, BASE, 0>(ring, coef, tw1, dst, t, [] {});
+                    chz768_fold2_ring<P, BASE, 2>(ring, coef, tw1, dst, t, [] {});
+                    chz768_loads_generic<BASE>(ring, in, F, t);
+                } else {
+                    chz768_fold2_ring<P, BASE, 0>(ring, coef, tw1, dst, t, [&] { chz768_loads_a<BASE, true>(ring, in, F, t); });
+                    chz768_ring_wait<BASE, 2>(ring);
+                    chz768_fold2_ring<P, BASE, 2>(ring, coef, tw1, dst, t, [&] { chz768_loads_b<BASE, true>(ring, in, F, t); });
+                }
+                CHZ_STAMP(h, 2);
+            }
+            CHZ_STAMP(h, 3);
+            __syncthreads();
+            CHZ_STAMP(h, 4);
+        };
+        constexpr int PERIOD = 4;                                 // half-steps until the ring is back where it started (three slots per half-step, twelve slots)
+        auto run_steps = [&](auto edgec, int hb, int he) __attribute__((always_inline)) {        // half-steps [hb, he); hb is a multiple of the ring's period
+            for (int h = hb; h < he; h += PERIOD) {
+                half_step(std::integral_constant<int, 0>{}, edgec, h);
+                if (h + 1 >= he) break;
+                half_step(std::integral_constant<int, 3>{}, edgec, h + 1);
+                if (h + 2 >= he) break;
+                half_step(std::integral_constant<int, 6>{}, edgec, h + 2);
+                if (h + 3 >= he) break;
+                half_step(std::integral_constant<int, 9>{}, edgec, h + 3);
+            }
+        };
+        // half-step h loads frames of the half-steps h + 1 (from its third frame on) and h + 2: the fast loader is right once the
+        // first frame of half-step h + 1 lies inside the new block
+        // (The unfused form -- a checking mode -- runs every half-step as an edge step at this decimation: with its epilogue's row
+        // addresses the kernel does not fit 168 registers, and what the compiler chose to spill were ring slots with a load in flight
+        // -- it stores the stale value and reloads it behind the wait; tests/test_cpu_inflight_loads.py scans for exactly that.  One
+        // drained batch of twelve loads per half-step is a third of the fast loader's speed, and the arithmetic is the same.)
+        int h_edge = 0;
+        if (IQ || in.nsamp < D) h_edge = nsteps;
+        else if ((fs + NB) * D < in.lead) {
+            const int64_t need = (in.lead + D - 1) / D - (fs + NB);
+            h_edge = (int)((need + NB - 1) / NB);
+            h_edge = (h_edge + PERIOD - 1) / PERIOD * PERIOD;
+            if (h_edge > nsteps) h_edge = nsteps;
+        }
+        run_steps(std::true_type{}, 0, h_edge);
+        if constexpr (!IQ) run_steps(std::false_type{}, h_edge, nsteps);
+        } else {
         cf2 ring[4][P + 4];                                       // delay lines + the inputs of this and the next half-step
         {
             const int64_t vend = fs * D;                          // multiple of M (fs is even)
@@ -848,7 +1097,7 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
             for (int jb = 0; jb < 4; jb++) {
                 const int64_t vlast = vend - M + (t + 256 * jb);
 #pragma unroll
-                for (int q = 0; q < P; q++) ring[jb][q] = in.generic(vlast - (int64_t)M * (P - 1 - q));
+                for (int q = 0; q < P; q++) ring[jb][q] = in.generic_nb(vlast - (int64_t)M * (P - 1 - q));
             }
         }
         chz_load_half_ring<P, 0, P, false>(ring, in, fs, t);
@@ -912,7 +1161,7 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
         };
         // half-step h loads the frames of half-step h + 2: the fast loader is right once those lie inside the new block
         int h_edge = 0;
-        if (in.nsamp < CHZ_D) h_edge = nsteps;
+        if (in.nsamp < D) h_edge = nsteps;
         else if ((fs + 2 * NB) * D < in.lead) {
             const int64_t need = (in.lead + D - 1) / D - (fs + 2 * NB);           // frames from the first loaded one to the first inside the block
             h_edge = (int)((need + NB - 1) / NB);
@@ -921,6 +1170,7 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
         }
         run_steps(std::true_type{}, 0, h_edge);
         run_steps(std::false_type{}, h_edge, nsteps);
+        }
         CHZ_TL_FLUSH;
     } else if (role == 1) {
         // ------------------------------------------------------------------ pass-2 role (+ pass 3 when P3_WITH_P2)
@@ -950,7 +1200,7 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
 #pragma unroll
             for (int r = 1; r < 16; r++) tw3[r - 1] = chz_twiddle(r * p3_i, 1024);
         }
-        ChzSlicer<SL, IQ> slicer;
+        ChzSlicer<SL, IQ, SPS> slicer;
         slicer.init(a, wf, lane);
         __syncthreads();                                          // all roles start together 
         {
@@ -1006,6 +1256,7 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
 struct ChannelizerState {
     bool enabled = false;
     int P = 8;
+    int D = CHZ_D;                  // input samples per frame: 512 (3 samples per symbol) or 768 (2)
     uint32_t C = 0, first_bin = 0;  // rows this handle decodes (= the band's channels, or one group of them), FFT bin of the band's channel 0
     uint32_t groups = 1, group = 0; // cfg.wideband_groups / wideband_group
     uint16_t *bin2row = nullptr;    // device [M]
@@ -1031,11 +1282,14 @@ inline double bessel_i0(double x)
     return s;
 }
 
-// Kaiser(beta = 8) windowed sinc, cutoff 13 kHz at fs = M * 30 kHz, unit DC gain
-inline std::vector<float> chz_design_taps(int P)
+// Kaiser(beta = 8) windowed sinc at fs = M * 30 kHz, unit DC gain; -6 dB at 13 kHz behind the D = 512 bank, at 15 kHz behind the D = 768 one
+// (40 ksps per channel leave the slicer two sampling phases per symbol instead of three: the wider pass band gives back, under a
+// carrier offset, what the coarser timing costs -- profiles/r06/decim768_cpu_gonogo.txt; oracle/channelizer.py: cutoff_for_decim)
+inline double chz_cutoff_hz(int D) { return D == CHZ_D768 ? 15.0e3 : 13.0e3; }
+inline std::vector<float> chz_design_taps(int P, int D = CHZ_D)
 {
     const int L = P * CHZ_M;
-    const double fc = 13.0e3 / (CHZ_M * 30.0e3);      // cycles per sample
+    const double fc = chz_cutoff_hz(D) / (CHZ_M * 30.0e3);      // cycles per sample
     const double beta = 8.0, i0b = bessel_i0(beta);
     std::vector<double> h(L);
     double sum = 0.0;
@@ -1053,17 +1307,17 @@ inline std::vector<float> chz_design_taps(int P)
     return out;
 }
 
-inline uint32_t chz_hist(int P) { return (uint32_t)(P * CHZ_M - CHZ_D + CHZ_PRE * CHZ_D); }
-inline size_t chz_carry_cap(int P) { return (size_t)chz_hist(P) + 64 * CHZ_D; }   // + leftover (< 64 frames)
+inline uint32_t chz_hist(int P, int D) { return (uint32_t)(P * CHZ_M - D + CHZ_PRE * D); }
+inline size_t chz_carry_cap(int P, int D) { return (size_t)chz_hist(P, D) + 64 * D; }   // + leftover (< 64 frames)
 
 inline int channelizer_reset(ChannelizerState &z, hipStream_t s)
 {
     if (!z.enabled) return 0;
-    const size_t cap = chz_carry_cap(z.P);
+    const size_t cap = chz_carry_cap(z.P, z.D);
     if (hipMemsetAsync(z.carry[0], 0, sizeof(float2) * cap, s) != hipSuccess) return -EIO;
     if (hipMemsetAsync(z.carry[1], 0, sizeof(float2) * cap, s) != hipSuccess) return -EIO;
     z.carry_cur = 0;
-    z.carry_len = chz_hist(z.P);                     // all-zero history, no leftover
+    z.carry_len = chz_hist(z.P, z.D);                // all-zero history, no leftover
     z.frames_done = 0;
     return 0;
 }
@@ -1099,25 +1353,25 @@ inline int chz_rows(const amps_recc_cfg_t &cfg, std::vector<uint16_t> *bin2row, 
 
 inline int channelizer_create(ChannelizerState &z, const amps_recc_cfg_t &cfg, hipStream_t s)
 {
-    if (cfg.wideband_channels != CHZ_M || cfg.wideband_decim != CHZ_D) return -EINVAL;   // M = 1024, D = 512
+    if (cfg.wideband_channels != CHZ_M || (cfg.wideband_decim != CHZ_D && cfg.wideband_decim != CHZ_D768)) return -EINVAL;   // M = 1024, D = 512 or 768
     const int P = cfg.wideband_taps_per_branch ? (int)cfg.wideband_taps_per_branch : 8;
     if (P != 8) return -EINVAL;                                   // the register ring of chz12_kernel is laid out for eight taps per branch
     if (cfg.n_channels > CHZ_M || cfg.wideband_first_channel >= CHZ_M || cfg.max_samples_per_push == 0) return -EINVAL;
     std::vector<uint16_t> b2r;
     const int rows = chz_rows(cfg, &b2r, &z.row2chan);
     if (rows < 1) return rows < 0 ? rows : -EINVAL;
-    z.P = P; z.C = (uint32_t)rows; z.first_bin = cfg.wideband_first_channel;
+    z.P = P; z.D = (int)cfg.wideband_decim; z.C = (uint32_t)rows; z.first_bin = cfg.wideband_first_channel;
     z.groups = cfg.wideband_groups > 1 ? cfg.wideband_groups : 1u; z.group = cfg.wideband_group;
     if (hipMalloc((void **)&z.bin2row, sizeof(uint16_t) * CHZ_M) != hipSuccess) return -ENOMEM;
     if (hipMemcpy(z.bin2row, b2r.data(), sizeof(uint16_t) * CHZ_M, hipMemcpyHostToDevice) != hipSuccess) return -EIO;
     z.max_frames = cfg.max_samples_per_push;
     z.ld = ((uint64_t)z.max_frames + 7) & ~7ull;
     const size_t L = (size_t)P * CHZ_M;
-    std::vector<float> h = chz_design_taps(P);
+    std::vector<float> h = chz_design_taps(P, z.D);
     if (hipMalloc((void **)&z.taps, sizeof(float) * L) != hipSuccess) return -ENOMEM;
     if (hipMemcpy(z.taps, h.data(), sizeof(float) * L, hipMemcpyHostToDevice) != hipSuccess) return -EIO;
-    if (hipMalloc((void **)&z.carry[0], sizeof(float2) * chz_carry_cap(P)) != hipSuccess) return -ENOMEM;
-    if (hipMalloc((void **)&z.carry[1], sizeof(float2) * chz_carry_cap(P)) != hipSuccess) return -ENOMEM;
+    if (hipMalloc((void **)&z.carry[0], sizeof(float2) * chz_carry_cap(P, z.D)) != hipSuccess) return -ENOMEM;
+    if (hipMalloc((void **)&z.carry[1], sizeof(float2) * chz_carry_cap(P, z.D)) != hipSuccess) return -ENOMEM;
     // z.out (the channel-major block, C x ld x 8 B: 1.7 GB for a full band at 2^18 frames per push) is allocated by the first
     // unfused / debug run: the fused form never touches it
     {
@@ -1156,17 +1410,17 @@ inline int channelizer_run(ChannelizerState &z, const float2 *iq, size_t nsamp, 
         d = z.stage;
     }
     if (!fused && !z.out && hipMalloc((void **)&z.out, sizeof(float2) * (size_t)z.C * z.ld) != hipSuccess) return -ENOMEM;
-    const uint32_t hist = chz_hist(z.P);
+    const uint32_t hist = chz_hist(z.P, z.D);
     const uint32_t leftover = z.carry_len - hist;
     const uint64_t avail = (uint64_t)leftover + nsamp;
-    // frames consumed: even (keeps the frame parity of a launch at 0), and in the fused form a multiple of 64
-    // (whole words of the RECC bit ring); the rest waits in the carry
-    const uint32_t nframes = (uint32_t)(avail / CHZ_D) & (fused ? ~63u : ~1u);
+    // frames consumed: a multiple of four (a launch starts where the stream position is a multiple of M: frame parity 0 at D = 512,
+    // frame phase 0 of 4 at D = 768), and in the fused form a multiple of 64 (whole words of the RECC bit ring); the rest waits in the carry
+    const uint32_t nframes = (uint32_t)(avail / (uint32_t)z.D) & (fused ? ~63u : z.D == CHZ_D ? ~1u : ~3u);
     if (nframes > z.max_frames) return -E2BIG;
 #ifdef CHZ_TIMELINE
     unsigned long long *a_tl_last = nullptr;
 #endif
-    const uint32_t consumed = nframes * CHZ_D;                        // virtual samples consumed (incl. leftover)
+    const uint32_t consumed = nframes * (uint32_t)z.D;                // virtual samples consumed (incl. leftover)
     const uint32_t new_left = (uint32_t)(avail - consumed);
     bool carry_in_kernel = false;
     if (nframes) {
@@ -1193,6 +1447,13 @@ inline int channelizer_run(ChannelizerState &z, const float2 *iq, size_t nsamp, 
         a.tl = tl_dev;
         a_tl_last = tl_dev;
 #endif
+        if (z.D == CHZ_D768) {
+            if (!fused) hipLaunchKernelGGL((chz12_kernel<8, CHZ12_IQ, CHZ_D768>), g12, b12, 0, s, a);
+            else if (slicer == AMPS_SLICER_PRODUCT) hipLaunchKernelGGL((chz12_kernel<8, AMPS_SLICER_PRODUCT, CHZ_D768>), g12, b12, 0, s, a);
+            else if (slicer == AMPS_SLICER_SINE) hipLaunchKernelGGL((chz12_kernel<8, AMPS_SLICER_SINE, CHZ_D768>), g12, b12, 0, s, a);
+            else if (slicer == AMPS_SLICER_EXACT) hipLaunchKernelGGL((chz12_kernel<8, AMPS_SLICER_EXACT, CHZ_D768>), g12, b12, 0, s, a);
+            else hipLaunchKernelGGL((chz12_kernel<8, AMPS_SLICER_ATAN_BOXCAR, CHZ_D768>), g12, b12, 0, s, a);
+        } else
         if (!fused) hipLaunchKernelGGL((chz12_kernel<8, CHZ12_IQ>), g12, b12, 0, s, a);
         else if (slicer == AMPS_SLICER_PRODUCT) hipLaunchKernelGGL((chz12_kernel<8, AMPS_SLICER_PRODUCT>), g12, b12, 0, s, a);
         else if (slicer == AMPS_SLICER_SINE) hipLaunchKernelGGL((chz12_kernel<8, AMPS_SLICER_SINE>), g12, b12, 0, s, a);

@@ -301,10 +301,17 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2, 3
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
-template <class Sync>
+// TWO = two samples per symbol (sps == 2, the wideband seam at D = 768), where the rule is another one (capture() of
+// oracle/fused_model.c): ONE slicer bit lies between the two instants of a pair -- it says which side the transition was on, not how
+// far -- so a block is taken at whichever of the delays d - 1, d, d + 1 (d = the block before) shows the fewest Manchester violations
+// (a == b) in the block ITSELF; d wins a tie, then d - 1.  Same rounds, same one wave sum (three 8-bit counts), and the same trick
+// for the chain: the window of block b + 1 is fetched TWO samples early at the delay block b starts from, so whatever block b decides
+// (-1, 0, +1) the five bits block b + 1 looks at start 0, 1 or 2 bits into it.
+template <class Sync, bool TWO = false>
 __device__ __forceinline__ void manchester_from_ring(DecodeCore &s, const uint64_t *ring, uint64_t nc, uint64_t w0, uint32_t sps, int lane, bool track,
                                                      bool keep_delays = true)
 {
+    constexpr int EARLY = TWO ? 2 : 1;                             // samples in front of a pair's first instant that a lane's window starts
     decode_core_begin(s, lane);
     Sync::sync();
     const uint32_t *r32 = (const uint32_t *)ring;
@@ -322,7 +329,7 @@ __device__ __forceinline__ void manchester_from_ring(DecodeCore &s, const uint64
     uint32_t badacc = 0u;
     // slicer bits from one before the first sampling instant of bit k at delay d (k, d from the caller; lanes beyond the block idle)
     auto fetch = [&](int k, int d, bool on) {
-        const uint32_t na = (uint32_t)(base + (int32_t)sps * (2 * k + 1) + d - 1);
+        const uint32_t na = (uint32_t)(base + (int32_t)sps * (2 * k + 1) + d - EARLY);
         const uint32_t q = on ? na >> 5 : 0u;
         f_lo = r32[q]; f_hi = r32[q + 1]; f_sh = na & 31u;
     };
@@ -339,6 +346,18 @@ __device__ __forceinline__ void manchester_from_ring(DecodeCore &s, const uint64
         const int lhs = E1 * n0 + E0 * n1, rhs = 2 * n0 * n1;
         if (rhs > 0) dly += lhs > rhs ? 1 : lhs < -rhs ? -1 : 0;
     };
+    // TWO: w starts one sample in front of the pair at the delay the block before was taken at; returns the block's own move
+    auto choose2 = [&](uint32_t w, bool on) -> int {
+        const uint32_t e = w ^ (w >> 2);                               // bit i clear: samples i and i + 2 are equal
+        const uint32_t contrib = on ? ((~e & 1u) | ((~e & 2u) << 7) | ((~e & 4u) << 14)) : 0u;   // violations at d - 1 | d << 8 | d + 1 << 16
+        const uint32_t tot = wave_sum_u32(contrib);
+        const uint32_t vm = tot & 0xffu, v0 = (tot >> 8) & 0xffu, vp = tot >> 16;
+        int mv = 0;
+        uint32_t best = v0;
+        if (vm < v0) { mv = -1; best = vm; }
+        if (vp < v0 && vp < best) mv = 1;
+        return mv;
+    };
     // ---- block 0: the 37 bits of the trigger, in front of the capture: measured only.  A trigger at the very start of a stream
     // puts the window of the leading lanes (partly) in front of the stream: an exact trigger by the one early bit of lane 0, which
     // is not used; a TOLERANT one (cfg.sync_tolerance) by up to its tolerated symbols.  What lies in front of the stream reads 1,
@@ -353,23 +372,36 @@ __device__ __forceinline__ void manchester_from_ring(DecodeCore &s, const uint64
         const uint32_t w = nas >= 0 ? __builtin_amdgcn_alignbit(r32[q + 1], r32[q], na & 31u) >> 1
                                     : sh >= 32 ? ~0u : ((r32[0] << (uint32_t)sh) | ((1u << (uint32_t)sh) - 1u));
         fetch(lane, 0, lane < 7 + AMPS_RECC_WORD_BITS);           // block 1 = bits 0 .. 54
+        if constexpr (TWO) {
+            // the window from one sample in front of the pair (nas), ones in front of the stream
+            const uint32_t w2 = nas >= 0 ? __builtin_amdgcn_alignbit(r32[q + 1], r32[q], na & 31u)
+                                         : sh + 1 >= 32 ? ~0u : ((r32[0] << (uint32_t)(sh + 1)) | ((1u << (uint32_t)(sh + 1)) - 1u));
+            if (track) dly += choose2(w2, on);
+            if (lane == 0 && keep_delays) s.dly[0] = (int8_t)dly;
+        } else {
         if (lane == 0 && keep_delays) s.dly[0] = 0;
         if (track) measure(w, on);
+        }
     }
     // ---- block 1: the coded DCC (bits 0..6) and repeat 0 of word 0
     {
         const int k = lane;
         const bool on = lane < 7 + AMPS_RECC_WORD_BITS;
-        const uint32_t w = __builtin_amdgcn_alignbit(f_hi, f_lo, f_sh) >> (uint32_t)(dly + 1);
-        if (lane == 0 && keep_delays) s.dly[1] = (int8_t)dly;
+        uint32_t w = __builtin_amdgcn_alignbit(f_hi, f_lo, f_sh) >> (uint32_t)(dly + 1);
         const int d1 = dly;
         fetch(7 + AMPS_RECC_WORD_BITS + lane, d1, lane < AMPS_RECC_WORD_BITS);
+        if constexpr (TWO) {                                       // w starts one sample in front of the pair at d1: the block picks its own delay
+            const int mv = track ? choose2(w, on) : 0;
+            dly += mv;
+            w >>= (uint32_t)(mv + 1);
+        }
+        if (lane == 0 && keep_delays) s.dly[1] = (int8_t)dly;
         const uint32_t sa = w & 1u, sb = (w >> sps) & 1u;
         if (on) s.bits[BOFF + k] = (uint8_t)(sa == sb ? (sa ^ 1u) : sb);
         const uint64_t bad = __ballot(on && sa == sb);
         if (lane == 0) s.bad[0] = (uint32_t)__popcll(bad & 0x7full);
         badacc = (uint32_t)__popcll(bad >> 7);
-        if (track) measure(w, on);
+        if constexpr (!TWO) { if (track) measure(w, on); }
         dly_fetched = d1;
     }
     // ---- blocks 2 .. 35: repeat r of word w (block = 1 + 5 w + r), 48 bits each
@@ -379,11 +411,16 @@ __device__ __forceinline__ void manchester_from_ring(DecodeCore &s, const uint64
     int rep = 1, word = 0;
 #pragma unroll 1
     for (int b = 2; b < AMPS_TRACK_BLOCKS; b++) {
-        const uint32_t w = __builtin_amdgcn_alignbit(f_hi, f_lo, f_sh) >> (uint32_t)(dly - dly_fetched + 1);
-        if (lane == 0 && keep_delays) s.dly[b] = (int8_t)dly;
+        uint32_t w = __builtin_amdgcn_alignbit(f_hi, f_lo, f_sh) >> (uint32_t)(dly - dly_fetched + 1);
         dly_fetched = dly;
         fetch(kn, dly, on48 && b + 1 < AMPS_TRACK_BLOCKS);        // (the last round fetches nothing it uses: q = 0)
         kn += AMPS_RECC_WORD_BITS;
+        if constexpr (TWO) {
+            const int mv = track ? choose2(w, on48) : 0;
+            dly += mv;
+            w >>= (uint32_t)(mv + 1);
+        }
+        if (lane == 0 && keep_delays) s.dly[b] = (int8_t)dly;
         const uint32_t sa = w & 1u, sb = (w >> sps) & 1u;
         if (on48) *bitp = (uint8_t)(sa == sb ? (sa ^ 1u) : sb);
         bitp += AMPS_RECC_WORD_BITS;
@@ -392,7 +429,7 @@ __device__ __forceinline__ void manchester_from_ring(DecodeCore &s, const uint64
             if (lane == 0) s.bad[1 + word] = badacc;
             badacc = 0u; rep = 0; word++;
         }
-        if (track) measure(w, on48);
+        if constexpr (!TWO) { if (track) measure(w, on48); }
     }
     Sync::sync();
 }

@@ -370,6 +370,19 @@ __host__ __device__ __forceinline__ uint32_t exact_slice_word3(uint32_t SX, uint
     wp_out = wp; wm_out = wm;
     return ~K.p[3] & (K.p[0] | K.p[1] | K.p[2] | ~SC);                  // K > 0, or K == 0 and Im(y conj(y[n-3])) not negative
 }
+// ... and two frames per symbol (the D = 768 bank): K = w'' - (w'[n] + w'[n-1]), -3 .. 3
+__host__ __device__ __forceinline__ uint32_t exact_slice_word2(uint32_t SX, uint32_t ST, uint32_t SC, uint32_t sx_prev, uint32_t wp_prev, uint32_t wm_prev,
+                                                                uint32_t &wp_out, uint32_t &wm_out)
+{
+    const uint32_t sx1 = exact_funnel(sx_prev, SX, 1), sx2 = exact_funnel(sx_prev, SX, 2);
+    const uint32_t wp = ~SX & sx1 & ST, wm = SX & ~sx1 & ~ST;
+    const uint32_t up = ~SX & sx2 & SC, um = SX & ~sx2 & ~SC;
+    const uint32_t wp1 = exact_funnel(wp_prev, wp, 1), wm1 = exact_funnel(wm_prev, wm, 1);
+    const SBits<2> t0 = { { wp | wm, wp } }, t1 = { { wp1 | wm1, wp1 } }, u = { { up | um, um } };
+    const SBits<3> K = sb_add<3>(sb_add<3>(t0, t1), u);
+    wp_out = wp; wm_out = wm;
+    return ~K.p[2] & (K.p[0] | K.p[1] | ~SC);                           // K > 0, or K == 0 and Im(y conj(y[n-2])) not negative
+}
 
 // BITS = true is the bit-domain form used behind the fused channelizer: the slicer bits of this launch are
 // already in the HBM ring (written by chz_fused_kernel), so a tile is just 16 dwords read from it and only the

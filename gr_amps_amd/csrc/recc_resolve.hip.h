@@ -92,12 +92,13 @@ __device__ __forceinline__ void capture_gather_wave(const ResolveArgs &a, uint32
     WaveSync::sync();
     tl.mark(8);
 }
+template <bool TWO>
 __device__ __forceinline__ void capture_decode_wave(const ResolveArgs &a, uint32_t c, uint64_t nc, uint64_t *scratch, int lane, RtlStamps tl = RtlStamps())
 {
     DecodeCore &k = *(DecodeCore *)scratch;
     const uint64_t *s_ring = scratch + (sizeof(DecodeCore) + 7) / 8;
     const uint64_t w0 = capture_first_word(nc, a.sps);
-    manchester_from_ring<WaveSync>(k, s_ring, nc, w0, a.sps, lane, a.track != 0, a.burst_syms != nullptr);
+    manchester_from_ring<WaveSync, TWO>(k, s_ring, nc, w0, a.sps, lane, a.track != 0, a.burst_syms != nullptr);
     tl.mark(0);
     decode_core_wave<WaveSync>(k, c, nc, nullptr, a.majority != 0, lane, tl);
 }
@@ -174,7 +175,8 @@ constexpr int RESOLVE_LDS_HITS_WIDE = 2048;
 // split into independent chains (see below).  0.72 ms -> 0.09 (LDS, one lane) -> parallel chains, for one channel x 2^26.
 // A batch of THREADS segments with more hits than the LDS window holds is walked in several passes (the hold-off state
 // carries from pass to pass exactly as it does from batch to batch), so no hit count overflows this kernel.
-template <int THREADS, int HITS>
+// TWO = two samples per symbol (a.sps == 2): the capture rule of the wideband seam at D = 768 (manchester_from_ring)
+template <int THREADS, int HITS, bool TWO = false>
 __global__ __launch_bounds__(THREADS, 4) void recc_resolve_kernel(ResolveArgs a)
 {
     __shared__ uint64_t s_hits[HITS];
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(THREADS, 4) void recc_resolve_kernel(ResolveArgs a)
                     __syncthreads();
                     if (tid == THREADS - 1) s_base = atomicAdd(a.nrecords, m);
                 }
-                if (mine) capture_decode_wave(a, (uint32_t)c, s_acc[i], scr, lane, st);
+                if (mine) capture_decode_wave<TWO>(a, (uint32_t)c, s_acc[i], scr, lane, st);
                 RTL(3);
                 __syncthreads();
                 RTL(4);
@@ -358,6 +360,7 @@ __global__ __launch_bounds__(THREADS, 4) void recc_resolve_kernel(ResolveArgs a)
 // channel x 2^26 samples holds 745 bursts, which the resolve kernel's one workgroup would decode four at a time (1.5 ms; here
 // 0.03).  With many channels the fused form wins: no queue, no second launch, no 2048 workgroups to dispatch.
 inline bool resolve_uses_queue(uint32_t n_channels) { return n_channels < 64; }
+template <bool TWO = false>
 __global__ __launch_bounds__(64) void recc_capture_kernel(ResolveArgs a)
 {
     extern __shared__ uint64_t s_cap[];                            // one resolve_cap_stride
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(64) void recc_capture_kernel(ResolveArgs a)
         capture_gather_wave(a, c, nc, s_cap, lane);
         uint32_t slot = 0;
         if (lane == 0) slot = atomicAdd(a.nrecords, 1u);
-        capture_decode_wave(a, c, nc, s_cap, lane);
+        capture_decode_wave<TWO>(a, c, nc, s_cap, lane);
         slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
         if (slot < a.rec_cap) capture_store_wave(a, nc, slot, s_cap, lane);
         else if (lane == 0) { atomicOr(a.status, 4u); __threadfence(); }   // rare: performed before this workgroup counts itself done

@@ -152,7 +152,9 @@ typedef struct amps_recc_cfg {
     int32_t  device;               /* HIP device ordinal, -1 = current device                             */
     uint32_t flags;                /* AMPS_RECC_FLAG_*                                                    */
     uint32_t wideband_channels;    /* channelizer seam: M branches: 1024 (0 = seam unused); other values: -EINVAL */
-    uint32_t wideband_decim;       /* channelizer seam: D input samples per output frame: 512 (2x oversampled)    */
+    uint32_t wideband_decim;       /* channelizer seam: D input samples per output frame: 512 (2x oversampled: 60 ksps per channel,
+                                    * samples_per_symbol = 3; the default of every tool here) or 768 (4/3 x oversampled: 40 ksps,
+                                    * samples_per_symbol = 2; 1.5 x fewer frames per input byte)                     */
     uint32_t wideband_taps_per_branch; /* prototype length = taps_per_branch * M: 8 (0 selects 8)              */
     uint32_t wideband_first_channel;   /* first FFT bin that is an active RECC channel                    */
     uint32_t sync_tolerance;       /* IQ / wideband seams: accept a trigger with up to this many of its 74

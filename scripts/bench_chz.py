@@ -10,16 +10,17 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 specs = sys.argv[2].split(",") if len(sys.argv) > 2 else ("atan", "sine", "product", "exact")
 warm = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 groups = int(sys.argv[4]) if len(sys.argv) > 4 else 0        # > 1: time ONE channel group of that many (a rank of the one-band multi-GPU split)
+decim = int(os.environ.get("CHZ_DECIM", "512"))             # 512 (3 samples per symbol) or 768 (2)
 NW = 1 << 27
 g = torch.Generator(device="cuda")
 g.manual_seed(1)
 x = torch.view_as_complex(torch.randn(NW, 2, device="cuda", generator=g) * 0.5)
 torch.cuda.synchronize()
-wb = {"channels": 1024, "decim": 512, "taps_per_branch": 8, "first_channel": 96}
+wb = {"channels": 1024, "decim": decim, "taps_per_branch": 8, "first_channel": 96}
 if groups > 1:
     wb.update(groups=groups, group=groups - 1)
 for spec in specs:
-    r = capi.Recc(n_channels=832, sps=3, max_samples=NW // 512 + 8, max_bursts=4096, time_kernels=True, wideband=wb, slicer=spec)
+    r = capi.Recc(n_channels=832, sps=1536 // decim, max_samples=NW // decim + 72, max_bursts=4096, time_kernels=True, wideband=wb, slicer=spec)
     for _ in range(warm):
         r.push_wideband(x)
         r.drain()

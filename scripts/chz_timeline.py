@@ -10,16 +10,17 @@ from gr_amps_amd import capi
 
 spec = sys.argv[1] if len(sys.argv) > 1 else "sine"
 NW = 1 << 27
+decim = int(os.environ.get("CHZ_DECIM", "512"))
 x = torch.view_as_complex(torch.randn(NW, 2, device="cuda") * 0.5)
 torch.cuda.synchronize()
-r = capi.Recc(n_channels=832, sps=3, max_samples=NW // 512 + 8, max_bursts=4096, slicer=spec,
-              wideband={"channels": 1024, "decim": 512, "taps_per_branch": 8, "first_channel": 96})
+r = capi.Recc(n_channels=832, sps=1536 // decim, max_samples=NW // decim + 72, max_bursts=4096, slicer=spec,
+              wideband={"channels": 1024, "decim": decim, "taps_per_branch": 8, "first_channel": 96})
 for _ in range(6):
     r.push_wideband(x)
     r.drain()
 tl = np.fromfile("/tmp/chz_tl.bin", dtype=np.uint64).reshape(12, 8).astype(np.float64)
 names = {0: "fold", 1: "pass2", 2: "p3+slicer"}
-print("spec %s, tag %s" % (spec, os.environ.get("AMPS_RECC_LIB", "").split("/")[-1]))
+print("decim %d spec %s, tag %s" % (decim, spec, os.environ.get("AMPS_RECC_LIB", "").split("/")[-1]))
 for w in range(12):
     role = 2 - (w >> 2)
     n = max(tl[w, 5], 1.0)
