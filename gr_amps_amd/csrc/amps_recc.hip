@@ -342,6 +342,7 @@ template <int SPS> int front_blocks_per_cu(int slicer, bool tol)   // of the ker
 int front_blocks_per_cu_for(uint32_t sps, int slicer, bool tol)
 {
     switch (sps) {
+    case 2: return front_blocks_per_cu<2>(slicer, tol);     // the two-kernel (unfused) form of the wideband seam at D = 768 only
     case 3: return front_blocks_per_cu<3>(slicer, tol);
     case 4: return front_blocks_per_cu<4>(slicer, tol);
     case 5: return front_blocks_per_cu<5>(slicer, tol);
@@ -365,6 +366,7 @@ bool sps_supported(uint32_t sps)
 int dispatch_front(uint32_t sps, const FrontArgs &fa, dim3 grid, hipStream_t s, int slicer)
 {
     switch (sps) {
+    case 2: launch_front<2>(fa, grid, s, slicer); break;
     case 3: launch_front<3>(fa, grid, s, slicer); break;
     case 4: launch_front<4>(fa, grid, s, slicer); break;
     case 5: launch_front<5>(fa, grid, s, slicer); break;

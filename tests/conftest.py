@@ -22,3 +22,17 @@ def gpu():
     from gr_amps_amd import capi
     capi.load()
     return torch.device("cuda:0")
+
+
+@pytest.fixture(params=[512, 768], ids=["D512", "D768"])
+def decim(request):
+    """input samples per filter-bank frame: 512 = the default form (60 ksps per channel, 3 samples per symbol), 768 = the 4/3 x
+    oversampled one (40 ksps, 2 samples per symbol)"""
+    return request.param
+
+
+def wb_cfg(decim, first, P=8, **kw):
+    """the `wideband=` dictionary of capi.Recc for a decimation, and the samples per symbol that go with it"""
+    d = {"channels": 1024, "decim": decim, "taps_per_branch": P, "first_channel": first}
+    d.update(kw)
+    return d, 1536 // decim

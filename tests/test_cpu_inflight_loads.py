@@ -42,6 +42,7 @@ def _touched(lines, rng, dst):
 
 
 LATCH = re.compile(r"\s*s_branch\s+(\.LBB\d+_\d+)")
+WAIT = re.compile(r"\s*s_waitcnt vmcnt\((\d+)\)")
 
 
 def scan(asm_text):
@@ -49,8 +50,11 @@ def scan(asm_text):
     loop's PATH: straight through the text, and at an unconditional `s_branch` to an EARLIER label (the loop's latch -- block
     placement rotates the loop, so its last half-step ends in that branch and not in the text that happens to follow it) on at the
     label.  Conditional branches are not taken: inside the loop they are its exits and the skips of its rare paths, wherever their
-    targets were placed.  The walk ends at the second `s_waitcnt vmcnt(8)` it meets, the wait that covers the load; nothing before
-    it may name one of the load's destination registers, and a walk that never gets there is reported too."""
+    targets were placed.  Vector memory returns in order, so `s_waitcnt vmcnt(N)` covers a load exactly when at least N younger
+    loads have been issued behind it (D = 512: vmcnt(8), the second wait the walk meets; D = 768: vmcnt(13), the third or fourth):
+    the walk counts the asm loads it passes and ends at the first wait whose N they reach.  Nothing before that may name one of the
+    load's destination registers -- a spill store of a ring slot is how round 6 met this -- and a walk that never gets there is
+    reported too."""
     txt = asm_text.split("\n")
     out, i = [], 0
     while i < len(txt):
@@ -67,23 +71,34 @@ def scan(asm_text):
             lm = re.match(r"^(\.LBB\d+_\d+):", l)
             if lm:
                 labels[lm.group(1)] = k
-        waits = [k for k, l in enumerate(lines) if "s_waitcnt vmcnt(8)" in l]
         loads = [(k, _regs(LOAD.match(l).group(1))) for k, l in enumerate(lines) if LOAD.match(l)]
-        # the unrolled loop that holds the asm loads: its waits are the ones with loads between them and their successor
+        # the manual waits of the unrolled loop that holds the asm loads: those with asm loads between them and their successor
+        waits = [k for k, l in enumerate(lines) if WAIT.match(l) and int(WAIT.match(l).group(1)) in (8, 13)]
         loop = [w for n, w in enumerate(waits) if any(w < k < (waits[n + 1] if n + 1 < len(waits) else w + 2000) for k, _ in loads)]
         issues = []
         for k, dst in loads:
-            pos, seen, latched = k + 1, 0, set()
-            while pos < len(lines) and seen < 2:
+            pos, younger, latched, covered, steps = k + 1, 0, set(), False, 0
+            while pos < len(lines) and steps < 50000:
+                steps += 1
                 t = lines[pos].strip()
-                if "s_waitcnt vmcnt(8)" in t:
-                    seen += 1
+                wm = WAIT.match(lines[pos])
+                lm = LOAD.match(lines[pos])
+                if wm and younger >= int(wm.group(1)):
+                    covered = True
+                    break
+                if lm:
+                    younger += 1
+                    if _regs(lm.group(1)) & dst:
+                        issues.append((m.group(1), k + 1, pos + 1, "loaded again before the covering wait: " + t))
+                        covered = True
+                        break
                 elif t and t[0] not in ";.":
                     used = set()
                     for tk in re.findall(r"v\[\d+:\d+\]|v\d+", t):
                         used |= _regs(tk)
                     if used & dst:
                         issues.append((m.group(1), k + 1, pos + 1, t))
+                        covered = True
                         break
                     bm = LATCH.match(lines[pos])
                     if bm and labels.get(bm.group(1), len(lines)) < pos and pos not in latched:
@@ -93,20 +108,25 @@ def scan(asm_text):
                     if "s_endpgm" in t:
                         break
                 pos += 1
-            else:
-                if seen < 2:
-                    issues.append((m.group(1), k + 1, pos, "path left the kernel before the covering wait"))
+            if not covered:
+                issues.append((m.group(1), k + 1, pos, "path left the kernel before the covering wait"))
         out.append((m.group(1), len(loads), len(loop), issues))
         i = j
     return out
 
 
 def test_scanner_sees_a_planted_hazard():
-    asm = "\n".join(["_ZN4amps12chz12_kernelXX:", ".LBB0_1:", "s_waitcnt vmcnt(8)", "global_load_dwordx2 v[10:11], v1, s[2:3]",
-                     "v_mov_b64_e32 v[20:21], v[10:11]", "s_cbranch_scc1 .LBB0_1", "s_barrier", "s_waitcnt vmcnt(8)",
+    asm = "\n".join(["_ZN4amps12chz12_kernelXX:", ".LBB0_1:", "s_waitcnt vmcnt(1)", "global_load_dwordx2 v[10:11], v1, s[2:3]",
+                     "v_mov_b64_e32 v[20:21], v[10:11]", "s_cbranch_scc1 .LBB0_1", "s_barrier", "s_waitcnt vmcnt(1)",
                      "global_load_dwordx2 v[12:13], v1, s[2:3]", "s_barrier", "s_branch .LBB0_1", "v_add_f32 v0, v10, v12", ".Lfunc_end0:"])
     res = scan(asm)
     assert len(res) == 1 and len(res[0][3]) == 1 and "v_mov_b64" in res[0][3][0][3]
+    # a spill store of a register whose load is in flight (what the D = 768 unfused kernel did before it lost its fast loader), and
+    # the same code with the store behind the wait that covers the load
+    bad = ["_ZN4amps12chz12_kernelYY:", ".LBB1_1:", "s_waitcnt vmcnt(1)", "global_load_dwordx2 v[10:11], v1, s[2:3]",
+           "scratch_store_dwordx2 off, v[10:11], off", "global_load_dwordx2 v[12:13], v1, s[2:3]", "s_waitcnt vmcnt(0)", "s_endpgm", ".Lfunc_end1:"]
+    good = bad[:4] + bad[5:7] + [bad[4]] + bad[7:]
+    assert any("scratch_store" in h[3] for h in scan("\n".join(bad))[0][3]) and not scan("\n".join(good))[0][3]
 
 
 @pytest.fixture(scope="module")
@@ -124,9 +144,14 @@ def asm_text():
 
 def test_no_register_with_a_load_in_flight_is_touched(asm_text):
     res = scan(asm_text)
-    assert len(res) == 5, [r[0] for r in res]                      # the unfused form and the four slicer specs
+    assert len(res) == 10, [r[0] for r in res]                     # the unfused form and the four slicer specs, at D = 512 and at D = 768
     for name, nloads, nwaits, issues in res:
-        assert nloads == 48 and nwaits == 6, (name, nloads, nwaits)   # six unrolled half-steps of eight loads
+        if "Li768E" in name and "Lin1E" in name:
+            assert nloads == 0, (name, nloads)                     # the unfused form at D = 768 has no fast loader (recc_channelizer.hip.h)
+        elif "Li768E" in name:
+            assert nloads == 48 and nwaits == 8, (name, nloads, nwaits)   # four unrolled half-steps of twelve loads and two waits
+        else:
+            assert nloads == 48 and nwaits == 6, (name, nloads, nwaits)   # six unrolled half-steps of eight loads
         assert not issues, (name, issues[:4])
 
 
@@ -151,7 +176,7 @@ def role_bodies_with_scratch(asm):
             lm = re.match(r"^(\.LBB\d+_\d+):", l)
             if lm:
                 cur = lm.group(1)
-                counts[cur] = {"fma": 0, "add": 0, "align": 0, "scratch": 0}
+                counts[cur] = {"fma": 0, "add": 0, "align": 0, "scratch": 0, "edge": 0}
                 continue
             if cur is None:
                 continue
@@ -161,7 +186,9 @@ def role_bodies_with_scratch(asm):
             c["add"] += t.startswith("v_pk_add_f32")
             c["align"] += t.startswith("v_alignbit_b32")
             c["scratch"] += t.startswith("scratch_")
-        bad += [(m.group(1), b, c) for b, c in counts.items() if c["scratch"] and (c["fma"] >= 100 or c["add"] >= 60 or c["align"] >= 20)]
+            c["edge"] += bool(re.match(r"global_load_dwordx2 v\[\d+:\d+\], v\[\d+:\d+\], off", t))
+        # (an EDGE half-step of the fold -- bounds-checked loads with 64-bit lane addresses: the head of a launch -- is no steady body)
+        bad += [(m.group(1), b, c) for b, c in counts.items() if c["scratch"] and not c["edge"] and (c["fma"] >= 100 or c["add"] >= 60 or c["align"] >= 20)]
         i = j
     return bad
 

@@ -7,12 +7,13 @@ import pytest
 from gr_amps_amd import capi, synth_wideband as sw
 
 pytestmark = pytest.mark.gpu
-D, FIRST, CW = 512, 96, 832
+FIRST, CW = 96, 832
+D = 512
 
 
-def _records(x, n, **wb):
-    with capi.Recc(n_channels=CW, sps=3, max_samples=n // D + 72, max_bursts=1024,
-                   wideband=dict({"channels": 1024, "decim": 512, "taps_per_branch": 8, "first_channel": FIRST}, **wb)) as r:
+def _records(x, n, D=512, **wb):
+    with capi.Recc(n_channels=CW, sps=1536 // D, max_samples=n // D + 72, max_bursts=1024,
+                   wideband=dict({"channels": 1024, "decim": D, "taps_per_branch": 8, "first_channel": FIRST}, **wb)) as r:
         for part in np.array_split(x, 3):                         # streaming pushes: the carry and the pre-roll are exercised too
             r.push_wideband(part)
         r.push_wideband(np.zeros(64 * D, np.complex64))
@@ -20,17 +21,18 @@ def _records(x, n, **wb):
 
 
 @pytest.mark.parametrize("G", [2, 4, 8])
-def test_groups_partition_the_band_and_reproduce_its_records(gpu, G):
+def test_groups_partition_the_band_and_reproduce_its_records(gpu, G, decim):
+    D = decim
     rng = np.random.default_rng(60 + G)
-    n = int(0.3 * sw.FS_WIDE) // D * D
+    n = int(0.3 * sw.FS_WIDE) // 1536 * 1536
     chans = sorted(set(int(c) for c in rng.integers(0, CW, 40)) | {0, 1, 7, 8, 63, 64, 415, 416, 831})
     planted = [((FIRST + c) % 1024, int(rng.integers(20000, n - 3456 * 1536 - 20000))) for c in chans]
     x, truth = sw.make_wideband(n, planted, seed=900 + G, snr_db=24.0)
-    whole = _records(x, n)
+    whole = _records(x, n, D)
     assert len(whole) == len(chans)
     parts, seen = [], set()
     for r in range(G):
-        got = _records(x, n, groups=G, group=r)
+        got = _records(x, n, D, groups=G, group=r)
         for g in got:                                             # every record belongs to this group: (bin mod 64) in the group's window
             k = (FIRST + int(g["channel"])) % 1024
             assert (k % 64) // (64 // G) == r

@@ -17,25 +17,25 @@ def test_random_streams_match_the_cpu_model(gpu, seed, resident):
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
-def test_wideband_random_schedules_give_the_one_shot_records(gpu, seed):
+def test_wideband_random_schedules_give_the_one_shot_records(gpu, seed, decim):
     """Wideband seam: whatever the push schedule (ragged sizes, host or device blocks, sync / split / no drains in between,
     fused or two-kernel form, exact or tolerant sync) the records equal those of one push with the same tolerance."""
     import numpy as np
     import torch
     from gr_amps_amd import capi, synth_wideband as sw
-    D = 512
+    D = decim
     rng = np.random.default_rng(seed)
     first, C = int(rng.integers(0, 1024)), 832
-    n = int(0.26 * sw.FS_WIDE) // D * D
+    n = int(0.26 * sw.FS_WIDE) // 1536 * 1536
     chans = rng.choice(C, size=6, replace=False)
     bursts = [((first + int(c)) % 1024, int(rng.integers(20000, 2200000))) for c in chans]
     x, truth = sw.make_wideband(n, bursts, seed=100 + seed)
-    wb = {"channels": 1024, "decim": 512, "taps_per_branch": 8, "first_channel": first}
+    wb = {"channels": 1024, "decim": D, "taps_per_branch": 8, "first_channel": first}
 
     spec = ("exact", "atan", "sine", "product")[seed % 4]      # the slicer spec under test rotates with the seed
 
     def run(schedule, unfused, tol, resident, mode):
-        with capi.Recc(n_channels=C, sps=3, max_samples=n // D + 72, max_bursts=64, unfused_wideband=unfused,
+        with capi.Recc(n_channels=C, sps=1536 // D, max_samples=n // D + 72, max_bursts=64, unfused_wideband=unfused,
                        sync_tolerance=tol, wideband=wb, slicer=spec) as r:
             off, recs, open_, keep = 0, [], False, []
             for m in schedule + [64 * D]:                      # the last block is silence: flushes the held-back frames

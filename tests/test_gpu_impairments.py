@@ -17,7 +17,7 @@ import oracle
 from gr_amps_amd import capi, synth, synth_wideband as sw
 
 pytestmark = pytest.mark.gpu
-FS, D, FIRST, CW = sw.FS_WIDE, 512, 96, 832
+FS, FIRST, CW = sw.FS_WIDE, 96, 832
 
 
 def _channels(C, sps, snr, ppm, cfo, seed0, n=None):
@@ -115,35 +115,38 @@ def test_iq_seam_decodes_what_the_reference_chain_decodes(gpu, ppm, cfo):
     assert sum(ref_ok) >= NBUR // 2, sum(ref_ok)            # the comparison is not vacuous: the restated chain decodes most of them
 
 
-@pytest.mark.parametrize("ppm,cfo", [(100, 2000), (-100, -2000), (500, 0)])
-def test_wideband_seam_decodes_what_the_reference_chain_decodes(gpu, ppm, cfo):
-    """sixteen channels of a 30.72 Msps block, every mobile off by the same symbol-clock / carrier offset, 30 dB: the wideband seam
-    (3 samples per symbol: 100 ppm is a whole sample phase by the end of the burst) decodes every burst, among them all that the
-    restated chain decodes from its own 400 ksps cut"""
+_WB_CACHE = {}
+
+
+def _wideband_case(torch, dev, ppm, cfo):
+    """the block of one (ppm, cfo) point and the restated chain's verdict on each of its 64 bursts, made once for both decimations"""
+    import widebandref
+    key = (ppm, cfo)
+    if key not in _WB_CACHE:
+        _WB_CACHE.clear()                                  # one 110 MB block at a time
+        n = int(0.45 * FS) // 1536 * 1536
+        chans = [13 * i + (i % 5) for i in range(64)]      # across the band, neighbours of the DC bin and both edges included
+        x, planted = widebandref.make_block(torch, dev, n, chans, FIRST, ppm, cfo, 30.0, seed=77)
+        ref = widebandref.reference_verdicts(x.cpu().numpy(), chans, FIRST, planted)
+        _WB_CACHE[key] = (n, chans, x, planted, ref)
+    return _WB_CACHE[key]
+
+
+@pytest.mark.parametrize("ppm,cfo,floor", [(100, 2000, 16), (500, 0, 48), (0, 0, 48)])
+def test_wideband_seam_decodes_what_the_reference_chain_decodes(gpu, ppm, cfo, floor, decim):
+    """sixty-four channels of a 30.72 Msps block at 30 dB, every mobile off by the same symbol-clock / carrier offset (signs alternating):
+    the wideband seam -- 3 samples per symbol at D = 512, where 100 ppm is a whole sample phase by the end of the burst, 2 at D = 768 --
+    decodes every burst, among them all that the restated chain decodes from its own 400 ksps cut.  Block and cuts are the same on every
+    box (tests/widebandref.py), so the number of bursts the restated chain decodes is a constant of the test: printed, and held to
+    a floor a single lucky burst cannot meet (VERDICT r05: >= 25 % of the bursts at +-2 kHz, >= 50 % without a carrier offset;
+    measured 27 of 64 at (100 ppm, 2 kHz), 64 at (500, 0) and (0, 0))."""
     import torch
-    n = int(0.45 * FS) // D * D
-    rng = np.random.default_rng(77)
-    g = torch.Generator(device=gpu)
-    g.manual_seed(77)
-    sigma = 10.0 ** (-30.0 / 20.0) / np.sqrt(2.0) * np.sqrt(FS / 30e3)
-    x = torch.view_as_complex(torch.randn(n, 2, device=gpu, generator=g, dtype=torch.float32) * float(sigma))
-    chans = [0, 1, 40, 120, 200, 300, 415, 416, 417, 500, 600, 700, 760, 829, 830, 831]
-    planted = {}
-    for c in chans:
-        k = (FIRST + c) % 1024
-        _, min10, _, _, words = synth.random_message(rng)
-        sym = synth.manchester(synth.burst_bits(words, dcc=int(rng.integers(0, 4)), rng=rng)).astype(np.float32) * 2 - 1
-        wave = synth.symbol_waveform(sym, 1536, float(ppm)).astype(np.float32)
-        off = int(rng.integers(40000, n - wave.size - 40000))
-        f = torch.from_numpy(wave).to(gpu) * (2 * np.pi * 8e3 / FS)
-        fc = 2 * np.pi * (sw.bin_freq(k) + cfo) / FS
-        ph = torch.cumsum(f.double() + fc, 0) + float(rng.uniform(0, 2 * np.pi)) + fc * off
-        x[off:off + wave.size] += torch.polar(torch.ones_like(ph, dtype=torch.float32), ph.remainder(2 * np.pi).float())
-        planted[c] = (min10, [list(w) for w in words])
-    wb = {"channels": 1024, "decim": 512, "taps_per_branch": 8, "first_channel": FIRST}
+    D = decim
+    n, chans, x, planted, ref = _wideband_case(torch, gpu, ppm, cfo)
+    wb = {"channels": 1024, "decim": D, "taps_per_branch": 8, "first_channel": FIRST}
     out = {}
     for fixed in (False, True):
-        with capi.Recc(n_channels=CW, sps=3, max_samples=n // D + 72, max_bursts=1024, wideband=wb, fixed_timing=fixed) as r:
+        with capi.Recc(n_channels=CW, sps=1536 // D, max_samples=n // D + 72, max_bursts=1024, wideband=wb, fixed_timing=fixed) as r:
             r.push_wideband(x)
             r.push_wideband(torch.zeros(64 * D, dtype=torch.complex64, device=gpu))
             recs = r.drain()
@@ -154,21 +157,10 @@ def test_wideband_seam_decodes_what_the_reference_chain_decodes(gpu, ppm, cfo):
     assert all(out[False].values()), [c for c in chans if not out[False][c]]
     if abs(ppm) >= 500:
         assert not all(out[True].values())                 # one fixed phase loses bursts at 500 ppm: the tracking is what decodes them
-    X = torch.fft.fft(x.to(torch.complex128))
-    nout = n * 5 // 384
-    nref = 0
-    for c in chans:
-        cbin = int(round((sw.bin_freq((FIRST + c) % 1024) - 160e3) / FS * n))
-        idx = (torch.arange(-nout // 2, nout // 2, device=gpu) + cbin) % n
-        y = (torch.fft.ifft(torch.fft.ifftshift(X[idx])) * (nout / n)).to(torch.complex64).cpu().numpy()
-        if _good(oracle.chain_iq400(y, 160e3, chunk=4096), *planted[c]):
-            nref += 1
-            assert out[False][c]
-    # (a floor against a vacuous comparison, not a property of the seam: at a 2 kHz carrier offset the restated chain's Mueller & Mueller
-    # loop locks or not on the last bits of rounding of the FFT-cut input -- 4, 3, 3 and once 1 of the 16 bursts on four boxes (rocFFT picks its
-    # kernels per box); round 5 saw 1 once where the floor was 2)
-    print("restated chain decoded %d of %d" % (nref, len(chans)))            # (pytest -rP shows it)
-    assert nref >= (len(chans) // 2 if cfo == 0 else 1), nref
+    nref = sum(ref.values())
+    print("restated chain decoded %d of %d at %d ppm, %d Hz" % (nref, len(chans), ppm, cfo))            # (pytest -rP shows it)
+    assert nref >= floor, nref
+    assert all(out[False][c] for c in chans if ref[c])
 
 
 def test_round4_golden_fixture_on_the_device(gpu):

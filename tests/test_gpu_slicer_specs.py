@@ -110,18 +110,19 @@ def test_product_slicer_words_equal_spec_a(gpu, snr, spec):
 
 
 @pytest.mark.parametrize("spec,sid", SPECS)
-def test_product_slicer_wideband_fused_unfused_and_cpu_model(gpu, spec, sid):
+def test_product_slicer_wideband_fused_unfused_and_cpu_model(gpu, spec, sid, decim):
     """wideband seam under spec B: fused kernel == two-kernel form == CPU model on the channelizer's own output"""
-    first, C = 96, 832
-    n = int(0.25 * sw.FS_WIDE) // D * D
+    first, C, D = 96, 832, decim
+    sps = 1536 // D
+    n = int(0.25 * sw.FS_WIDE) // 1536 * 1536
     planted = [(first + 3, 100000), (first + 417, 150000), (first + 830, 60000), (first + 831, 200000)]
     x, truth = sw.make_wideband(n, planted, seed=31)
-    wb = {"channels": 1024, "decim": 512, "taps_per_branch": 8, "first_channel": first}
-    with capi.Recc(n_channels=C, sps=3, max_samples=n // D + 72, max_bursts=64, wideband=wb) as r:
+    wb = {"channels": 1024, "decim": D, "taps_per_branch": 8, "first_channel": first}
+    with capi.Recc(n_channels=C, sps=sps, max_samples=n // D + 72, max_bursts=64, wideband=wb) as r:
         chan = r.debug_channelize(x)
     outs = []
     for unfused, chunks in ((False, [n]), (True, [n]), (False, [100000, 1, 4000000, n])):
-        with capi.Recc(n_channels=C, sps=3, max_samples=n // D + 72, max_bursts=64, wideband=wb, unfused_wideband=unfused,
+        with capi.Recc(n_channels=C, sps=sps, max_samples=n // D + 72, max_bursts=64, wideband=wb, unfused_wideband=unfused,
                        slicer=spec) as r:
             off = 0
             for m in chunks:
@@ -135,14 +136,14 @@ def test_product_slicer_wideband_fused_unfused_and_cpu_model(gpu, spec, sid):
     assert sorted(int(g["channel"]) for g in outs[0]) == sorted(k - first for k, _ in planted)
     assert outs[0].tobytes() == outs[1].tobytes() == outs[2].tobytes()
     active = sorted(int(g["channel"]) for g in outs[0])
-    want = oracle.fused_push_all(chan[active], sps=3, slicer=sid)
+    want = oracle.fused_push_all(chan[active], sps=sps, slicer=sid)
     want["channel"] = np.array(active, np.uint32)[want["channel"]]
     assert outs[0].tobytes() == want.tobytes()
     for (k, off), (kind, min10, esn, dialed, words) in truth.items():
         g = outs[0][active.index(k - first)]
         assert g["min"].decode() == min10 and g["valid"].all()
     # and the words equal those of spec A
-    with capi.Recc(n_channels=C, sps=3, max_samples=n // D + 72, max_bursts=64, wideband=wb) as r:
+    with capi.Recc(n_channels=C, sps=sps, max_samples=n // D + 72, max_bursts=64, wideband=wb) as r:
         r.push_wideband(x)
         r.push_wideband(np.zeros(64 * D, np.complex64))
         a = r.drain()

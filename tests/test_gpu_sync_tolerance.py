@@ -68,17 +68,17 @@ def test_tolerance_zero_and_nonzero_agree_on_clean_signals(gpu):
             assert np.array_equal(a["word_raw"], b["word_raw"]) and np.array_equal(a["word_dec"], b["word_dec"]) and a["min"] == b["min"]
 
 
-def test_tolerant_sync_on_the_wideband_seam(gpu):
+def test_tolerant_sync_on_the_wideband_seam(gpu, decim):
     """bit-domain correlator (behind the fused channelizer) with tolerance: same records as the two-kernel form, and as
     the exact correlator on undamaged bursts"""
-    first, C, D = 96, 832, 512
-    n = int(0.25 * sw.FS_WIDE) // D * D          # a burst lasts 0.173 s
+    first, C, D = 96, 832, decim
+    n = int(0.25 * sw.FS_WIDE) // 1536 * 1536    # a burst lasts 0.173 s
     bursts = [(first + 3, 120000), (first + 400, 90000), (first + 830, 200000)]
     x, truth = sw.make_wideband(n, bursts, seed=11)
     outs = []
     for k, unfused in ((0, False), (3, False), (3, True)):
-        with capi.Recc(n_channels=C, sps=3, max_samples=n // D + 72, max_bursts=64, unfused_wideband=unfused, sync_tolerance=k,
-                       wideband={"channels": 1024, "decim": 512, "taps_per_branch": 8, "first_channel": first}) as r:
+        with capi.Recc(n_channels=C, sps=1536 // D, max_samples=n // D + 72, max_bursts=64, unfused_wideband=unfused, sync_tolerance=k,
+                       wideband={"channels": 1024, "decim": D, "taps_per_branch": 8, "first_channel": first}) as r:
             r.push_wideband(x)
             r.push_wideband(np.zeros(64 * D, np.complex64))
             outs.append(r.drain())

@@ -14,7 +14,7 @@ import oracle
 from gr_amps_amd import capi, synth, synth_wideband as sw
 
 pytestmark = pytest.mark.gpu
-FS, D, FIRST, CW = sw.FS_WIDE, 512, 96, 832
+FS, FIRST, CW = sw.FS_WIDE, 96, 832
 BLEN = 3456 * 1536                                   # samples of one seizure burst at 30.72 Msps
 
 
@@ -47,9 +47,9 @@ def _cut400(torch, X, n, c):
     return (torch.fft.ifft(torch.fft.ifftshift(X[idx])) * (nout / n)).to(torch.complex64).cpu().numpy()
 
 
-def _gpu_records(x, n):
-    with capi.Recc(n_channels=CW, sps=3, max_samples=n // D + 72, max_bursts=1024,
-                   wideband={"channels": 1024, "decim": 512, "taps_per_branch": 8, "first_channel": FIRST}) as r:
+def _gpu_records(x, n, D):
+    with capi.Recc(n_channels=CW, sps=1536 // D, max_samples=n // D + 72, max_bursts=1024,
+                   wideband={"channels": 1024, "decim": D, "taps_per_branch": 8, "first_channel": FIRST}) as r:
         r.push_wideband(x)
         import torch
         r.push_wideband(torch.zeros(64 * D, dtype=torch.complex64, device=x.device))
@@ -65,17 +65,18 @@ def _good(recs, min10, words):
     return any(g["min"].decode() == min10 and g["valid"][:len(sent)].all() and [bytes(g["word_dec"][w]) for w in range(len(sent))] == sent for g in recs)
 
 
-def test_wideband_records_equal_the_reference_chain_channel_by_channel(gpu):
+def test_wideband_records_equal_the_reference_chain_channel_by_channel(gpu, decim):
     """twelve channels across the band (both edges, the centre, neighbours of the DC bin), one burst each at 30 dB: every burst
     the restated flow graph decodes from its own 400 ksps cut comes out of the wideband seam with the same fields and words"""
     import torch
-    n = int(0.45 * FS) // D * D
+    D = decim
+    n = int(0.45 * FS) // 1536 * 1536
     assert n % 384 == 0                                               # the 400 ksps cut (x 5 / 384) has a whole number of samples
     rng = np.random.default_rng(5)
     chans = [0, 1, 40, 200, 415, 416, 417, 600, 700, 829, 830, 831]
     bursts = [(c, int(rng.integers(40000, n - BLEN - 40000)), 0.0) for c in chans]
     x, truth = _block(torch, gpu, n, bursts, 30.0, seed=41)
-    got = _gpu_records(x, n)
+    got = _gpu_records(x, n, D)
     X = torch.fft.fft(x.to(torch.complex128))
     nref = 0
     for i, (c, off, _) in enumerate(bursts):
@@ -93,13 +94,14 @@ def test_wideband_records_equal_the_reference_chain_channel_by_channel(gpu):
 
 
 @pytest.mark.parametrize("spacing,levels,must", [(1, (0.0, 10.0, 20.0), 2), (2, (20.0, 30.0, 40.0), 2)])
-def test_overlapping_neighbour_bursts(gpu, spacing, levels, must):
+def test_overlapping_neighbour_bursts(gpu, spacing, levels, must, decim):
     """A weak burst (20 dB C/N) with a time-overlapping burst in the adjacent (30 kHz) or alternate (60 kHz) channel at +0 ... +40 dB:
     the reference's selectivity is its 299-tap channel filter (grc/recctest.grc:115-155), the wideband seam's is the prototype
-    of the filter bank (Kaiser beta 8, 13 kHz cutoff, 8 taps per branch).  The seam must decode the weak burst wherever the
+    of the filter bank (Kaiser beta 8, 8 taps per branch, -6 dB at 13 kHz at D = 512 and at 15 kHz at D = 768).  The seam must decode the weak burst wherever the
     restated reference chain does, and in any case at the first `must` levels (adjacent +0 / +10 dB, alternate +20 / +30 dB)."""
     import torch
-    n = int(0.45 * FS) // D * D
+    D = decim
+    n = int(0.45 * FS) // 1536 * 1536
     rng = np.random.default_rng(100 + spacing)
     bursts, weak = [], []
     for j, lvl in enumerate(levels):
@@ -111,7 +113,7 @@ def test_overlapping_neighbour_bursts(gpu, spacing, levels, must):
             bursts.append((c, off, 0.0))
             bursts.append((c + side * spacing, off + int(rng.integers(-600000, 600000)), lvl))   # overlaps >= 88 % of the weak burst
     x, truth = _block(torch, gpu, n, bursts, 20.0, seed=200 + spacing)
-    got = _gpu_records(x, n)
+    got = _gpu_records(x, n, D)
     X = torch.fft.fft(x.to(torch.complex128))
     table = {}
     for i, c, lvl in weak:
