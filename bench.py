@@ -70,6 +70,10 @@ def parse(argv=None):
     ap.add_argument("--groups", type=int, default=0, choices=[0, 2, 4, 8],
                     help="N = 1 only: run wideband832 as ONE rank of the one-band split over that many GPUs (cfg.wideband_groups: the rank decodes one "
                          "interleaved channel group and skips the last FFT pass and the slicer for the others' bins) -- the per-rank kernel time of --dist broadcast")
+    ap.add_argument("--decim", default="default", choices=["default", "512", "768"],
+                    help="wideband832: input samples per filter-bank frame -- 512 (2x oversampled, 3 samples per symbol) or 768 (4/3 x oversampled, 2 samples "
+                         "per symbol; DESIGN.md 4.2b); default = what the library uses when the caller does not say (amps_recc_default_wideband_decim)")
+    ap.add_argument("--no-other-decim", action="store_true", help="skip the pass of the same workload at the other decimation")
     ap.add_argument("--samples", type=int, default=0, help="per-channel samples per step (0 = workload default)")
     ap.add_argument("--taps", type=int, default=8, choices=[8], help="wideband832: prototype taps per polyphase branch")
     ap.add_argument("--prewarm-ms", type=float, default=400.0, help="untimed clock-settling run of the same step before the warmup steps")
@@ -241,6 +245,12 @@ def cpu_baseline(iq_base, sps, budget_s):
     }
 
 
+# what the 4/3 x oversampled bank costs in sensitivity against the default one (filled in from profiles/r06/decim768_sensitivity.txt)
+DECIM_SENSITIVITY = {"unit": "dB C/N in 30 kHz at 1 % burst loss, wideband seam, slicer spec D",
+                     "source": "profiles/r06/decim768_sensitivity.txt",
+                     "no_offset": {"D512": None, "D768": None}, "carrier_2kHz_clock_100ppm": {"D512": None, "D768": None}}
+
+
 # ----------------------------------------------------------------------------------------------------- flop / byte models
 def chz_flops_per_frame(taps, slicer, n_channels):
     """Algorithmic flops of the filter-bank kernel per frame (512 new wideband samples), as the kernel computes them:
@@ -338,7 +348,7 @@ class SmiSampler:
 
 
 # ----------------------------------------------------------------------------------------------------- one workload
-def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, warmup, light=False, dist_mode=None):
+def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, warmup, light=False, dist_mode=None, decim=None):
     """Build the resident batch, warm up, time exactly `steps` steps (barrier + synchronize on both sides,
     max over ranks) and return the result fields for this workload.  light = kernel time only (other slicer specs)."""
     from gr_amps_amd import capi
@@ -364,10 +374,11 @@ def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, w
         return out
     if wide:
         # config 3: the whole 832-channel band from one 30.72 Msps stream through the polyphase channelizer
-        sps, C, first_bin = 3, 832, 96
+        decim = int(decim or a.decim)
+        sps, C, first_bin = 1536 // decim, 832, 96
         NW = a.samples or (1 << 27)                       # wideband samples per step (1 GiB, 4.4 s of signal)
-        N = NW // 512                                     # samples per channel after the channelizer
-        wb = {"channels": 1024, "decim": 512, "taps_per_branch": a.taps, "first_channel": first_bin}
+        N = NW // decim                                   # samples per channel after the channelizer
+        wb = {"channels": 1024, "decim": decim, "taps_per_branch": a.taps, "first_channel": first_bin}
         n_band = C
         groups, group = (world, rank) if one_band else ((a.groups, a.groups - 1) if (a.groups and dist is None) else (0, 0))
         if groups in (2, 4, 8):
@@ -393,8 +404,8 @@ def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, w
         coll_ev = []                                      # torch.distributed modes: (start, end) events around the last steps' collectives
         expected = len(planted)
         iq_base = None
-        r = capi.Recc(n_channels=n_band, sps=sps, max_samples=N + 8, max_bursts=max(4096, 2 * expected), device=local, time_kernels=True,
-                      slicer=slicer, sync_torch=False, wideband=wb)
+        r = capi.Recc(n_channels=n_band, sps=sps, max_samples=N + 72, max_bursts=max(4096, 2 * expected), device=local, time_kernels=True,
+                      slicer=slicer, sync_torch=False, wideband=wb)                # (+ 72: at D = 768 a 2^27-sample block is no whole number of 64-frame groups, the rest waits in the carry)
         if abi_mode:                                      # the communicator lives in the handle; the id travels over the control plane
             ids = [capi.Recc.rccl_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
@@ -600,8 +611,8 @@ def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, w
     if wide:   # dominant kernel = the channelizer; algorithmic bytes = the wideband block read once (14.77 B/symbol at 832 channels)
         kms = tm["ms_channelizer"] / max(1, tm["launches_channelizer"])
         alg_bytes = 8.0 * NW
-        kname = "chz12_kernel<%d, slicer %s>" % (a.taps, SLICERS[slicer])
-        flops = chz_flops_per_frame(a.taps, slicer, C) * (NW / 512.0)
+        kname = "chz12_kernel<%d, slicer %s, D = %d>" % (a.taps, SLICERS[slicer], decim)
+        flops = chz_flops_per_frame(a.taps, slicer, C) * (NW / float(decim))
         note = ("filter bank (fold + FFT-1024 = 4 x 16 x 16) + slicer spec %s in one kernel, %.1f flop per input byte: bound by VALU issue "
                 "and LDS exchange, not by HBM (both rooflines are reported; the HBM fraction is what the metric asks for).  Only slicer bits "
                 "(1/64 of the input) reach HBM; the bit-domain correlator (ms_front) and the decode kernels follow" % (SLICERS[slicer], flops / alg_bytes))
@@ -619,7 +630,7 @@ def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, w
     ach = alg_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
     tfl = flops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
     drain_note = "" if a.no_pipeline else " (split drain: collected while the next step runs)"
-    prof = profile_traffic(name + ":" + slicer)
+    prof = profile_traffic(name + ":" + slicer + (":768" if wide and decim == 768 else ""))
     if wide and groups in (2, 4, 8):
         par = ("one band, %d interleaved channel groups (cfg.wideband_groups), this line = group %d: %d channels; every rank folds the whole stream, "
                "pass 3 of the FFT and the slicer run for the rank's own bins only%s"
@@ -633,12 +644,13 @@ def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, w
     res = {
         "value": round(value / 1e6, 3), "ms_per_step": round(el / steps * 1e3, 4),
         "config": {"workload": ("wideband832 (BASELINE configs[3]): one fc32 stream @30.72 Msps, %d samples per step per GPU -> 1024-branch "
-                                "polyphase channelizer -> 832 RECC channels @60 ksps -> fused slicer (numeric spec %s) + sync + BCH(63,51) decode, "
-                                "records drained every step%s" % (NW, SLICERS[slicer], drain_note)) if wide else
+                                "polyphase channelizer (D = %d) -> 832 RECC channels @%d ksps -> fused slicer (numeric spec %s) + sync + BCH(63,51) decode, "
+                                "records drained every step%s" % (NW, decim, 30720 // decim, SLICERS[slicer], drain_note)) if wide else
                                ("%s (BASELINE configs[1] batched): %d RECC channels x %d fc32 IQ samples @200 ksps per step per GPU, channel-major, "
                                 "fused slicer (numeric spec %s) + sync + BCH(63,51) decode, records drained every step%s"
                                 % (name, C, N, SLICERS[slicer], drain_note)),
                    "channels_per_gpu": C, "samples_per_channel": N, "samples_per_symbol": sps, "slicer_spec": SLICERS[slicer],
+                   **({"wideband_decim": decim} if wide else {}),
                    "algorithmic_bytes_per_symbol": round(alg_bytes / syms_per_step_rank, 2),
                    "realtime_channels_per_gpu": round(value / world / 20e3, 1),
                    **({"records_gathered_at_rank0_in_one_step": gathered} if gathered is not None else {}),
@@ -756,9 +768,14 @@ def main(argv=None):
     is_default = a.slicer in ("default", lib_default)
     if a.slicer == "default":
         a.slicer = lib_default
+    lib_decim = int(capi.load().amps_recc_default_wideband_decim())
+    decim_is_default = a.decim in ("default", str(lib_decim))
+    a.decim = lib_decim if a.decim == "default" else int(a.decim)
     broken_group = False
     res, iq_base = run_workload(a.workload, a, torch, dev, dist, rank, world, local, a.slicer, a.steps, a.warmup)
     res["config"]["slicer_is_library_default"] = is_default
+    if a.workload == "wideband832":
+        res["config"]["decim_is_library_default"] = decim_is_default
     res["config"]["slicer_sensitivity"] = SLICER_SENSITIVITY
     out = {
         "metric": "AMPS RECC Manchester symbols demodulated+decoded per second (real-time channels = value/0.02); achieved HBM GB/s vs peak",
@@ -779,6 +796,15 @@ def main(argv=None):
                 o, _ = run_workload(a.workload, a, torch, dev, None, 0, 1, local, sp, 20, 3, light=True)
                 other[SLICERS[sp]] = o
         out["other_slicer_specs"] = other
+    if world == 1 and a.workload == "wideband832" and not a.no_other_decim:
+        # the same workload at the other decimation of the filter bank: the library default (D = 512, three samples per symbol: the most
+        # sensitive form) and the 4/3 x oversampled bank (D = 768, two samples per symbol: 1.5 x fewer frames per input byte) side by side
+        od = 768 if a.decim == 512 else 512
+        o_steps = min(a.steps, 2000)
+        o, _ = run_workload("wideband832", a, torch, dev, None, 0, 1, local, a.slicer, o_steps, a.warmup, decim=od)
+        out["other_decim"] = {"wideband_decim": od, "value": o["value"], "unit": "Msym/s", "steps": o_steps, "ms_per_step": o["ms_per_step"], "config": o["config"],
+                              "roofline": o["roofline"], "roofline_compute": o["roofline_compute"], "power": o.get("power"),
+                              "sensitivity": DECIM_SENSITIVITY}
     if world == 1 and a.secondary != "none" and a.secondary != a.workload:
         sec_steps = min(a.steps, 2000)
         sec, sec_base = run_workload(a.secondary, a, torch, dev, None, 0, 1, local, a.slicer, sec_steps, a.warmup)
@@ -839,7 +865,7 @@ def main(argv=None):
                 out[key] = {"workload": "wideband832, one band over all ranks (%s)" % label, "value": b["value"], "unit": "Msym/s", "steps": bsteps,
                             "ms_per_step": b["ms_per_step"], "scaling": "strong", "config": b["config"],
                             "collective": dict(b.get("collective") or {}, backend=dist.get_backend(), nranks=dist.get_world_size(),
-                                               bytes_per_step=8 * b["config"]["samples_per_channel"] * 512),
+                                               bytes_per_step=8 * b["config"]["samples_per_channel"] * b["config"]["wideband_decim"]),
                             "kernel_ms_per_rank": [round(float(k), 4) for k in allk.tolist()], "ranks": gather_identities(b.get("identity")),
                             "roofline_rank0": b["roofline"]}
             except Exception as e:                                             # noqa: BLE001 -- recorded, see above

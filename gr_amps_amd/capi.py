@@ -108,7 +108,7 @@ EXPORTS = (
     "amps_recc_set_xlate", "amps_recc_push_raw", "amps_recc_debug_xlate", "amps_recc_set_timing",
     "amps_recc_drain_begin", "amps_recc_drain_end", "amps_recc_set_origin",
     "amps_recc_wait_event", "amps_recc_record_event", "amps_recc_refchain_symbols", "amps_recc_refchain_tables",
-    "amps_recc_drain_bursts", "amps_recc_default_slicer", "amps_recc_debug_exact_slice",
+    "amps_recc_drain_bursts", "amps_recc_default_slicer", "amps_recc_default_wideband_decim", "amps_recc_debug_exact_slice",
     "amps_recc_rccl_unique_id", "amps_recc_rccl_init", "amps_recc_push_wideband_bcast", "amps_recc_drain_gather",
     "amps_recc_push_wideband_dist", "amps_recc_rccl_info", "amps_recc_rccl_abort", "amps_recc_rccl_set_timeout",
 )
@@ -139,6 +139,8 @@ def load():
     L.amps_recc_abi_version.restype = C.c_int
     if hasattr(L, "amps_recc_default_slicer"):      # absent only from A/B builds of earlier revisions (AMPS_RECC_LIB)
         L.amps_recc_default_slicer.restype = C.c_int
+    if hasattr(L, "amps_recc_default_wideband_decim"):
+        L.amps_recc_default_wideband_decim.restype = C.c_uint32
     L.amps_recc_strerror.argtypes = [C.c_int]
     L.amps_recc_strerror.restype = C.c_char_p
     L.amps_recc_burst_size.restype = C.c_size_t
@@ -181,7 +183,7 @@ def load():
     L.amps_bch_encode_words.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, vp]
     L.amps_bch_decode_words.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, vp, vp, vp]
     for name in EXPORTS:
-        if name in ("amps_recc_default_slicer", "amps_recc_debug_exact_slice", "amps_recc_rccl_unique_id", "amps_recc_rccl_init",
+        if name in ("amps_recc_default_slicer", "amps_recc_default_wideband_decim", "amps_recc_debug_exact_slice", "amps_recc_rccl_unique_id", "amps_recc_rccl_init",
                     "amps_recc_push_wideband_bcast", "amps_recc_drain_gather") + _NEW_IN_ABI4 and not hasattr(L, name):
             continue
         if name not in ("amps_recc_strerror", "amps_recc_burst_size", "amps_recc_destroy"):   # every other entry point returns int
@@ -217,7 +219,7 @@ def _as_ptr(x, sync_torch=True):
 class Recc:
     """One handle = `n_channels` independent RECC receivers on one MI355X."""
 
-    def __init__(self, n_channels=1, sps=10, max_samples=0, max_bursts=1024, device=-1, time_kernels=False,
+    def __init__(self, n_channels=1, sps=None, max_samples=0, max_bursts=1024, device=-1, time_kernels=False,
                  stream=None, wideband=None, majority=False, unfused_wideband=False, sync_tolerance=0, slicer="default",
                  sync_torch=True, keep_bursts=False, fixed_timing=False):
         L = load()
@@ -226,6 +228,15 @@ class Recc:
         self.slicer = SLICER_NAMES[L.amps_recc_default_slicer() if hasattr(L, "amps_recc_default_slicer") else 0] if _SLICER_FLAGS[slicer] == 0 else \
             {FLAG_SLICER_ATAN: "atan", FLAG_SLICER_PRODUCT: "product", FLAG_SLICER_SINE: "sine", FLAG_SLICER_EXACT: "exact"}[_SLICER_FLAGS[slicer]]
         self.sync_torch = sync_torch
+        if wideband:
+            # "decim" absent / 0 = the library default; the samples per symbol follow the decimation unless they are given
+            wideband = dict(wideband)
+            if not wideband.get("decim"):
+                wideband["decim"] = int(L.amps_recc_default_wideband_decim()) if hasattr(L, "amps_recc_default_wideband_decim") else 512
+            if sps is None:
+                sps = 1536 // int(wideband["decim"])
+        elif sps is None:
+            sps = 10
         cfg = Cfg()
         cfg.struct_size = C.sizeof(Cfg)
         cfg.n_channels = n_channels
@@ -247,6 +258,7 @@ class Recc:
             cfg.wideband_groups = wideband.get("groups", 0)
             cfg.wideband_group = wideband.get("group", 0)
         self.n_channels, self.sps, self.max_bursts, self.max_samples = n_channels, sps, max_bursts, max_samples
+        self.decim = int(wideband["decim"]) if wideband else None
         self._h = C.c_void_p()
         rc = L.amps_recc_create(C.byref(self._h), C.byref(cfg))
         if rc != 0:

@@ -507,6 +507,7 @@ extern "C" {
 
 int amps_recc_abi_version(void) { return AMPS_RECC_ABI_VERSION; }
 int amps_recc_default_slicer(void) { return AMPS_SLICER_DEFAULT; }
+uint32_t amps_recc_default_wideband_decim(void) { return (uint32_t)CHZ_D; }
 size_t amps_recc_burst_size(void) { return sizeof(amps_recc_burst_t); }
 
 const char *amps_recc_strerror(int code)
@@ -529,11 +530,18 @@ const char *amps_recc_strerror(int code)
     }
 }
 
-int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg)
+int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg_in)
 {
-    if (!out || !cfg) return -EINVAL;
+    if (!out || !cfg_in) return -EINVAL;
     *out = nullptr;
-    if (cfg->struct_size != sizeof(amps_recc_cfg_t)) return -EINVAL;
+    if (cfg_in->struct_size != sizeof(amps_recc_cfg_t)) return -EINVAL;
+    amps_recc_cfg_t cfg_v = *cfg_in;                                  // wideband handles: decimation 0 = the library default, samples per symbol 0 = what goes with it
+    if (cfg_v.wideband_channels) {
+        if (cfg_v.wideband_decim == 0) cfg_v.wideband_decim = amps_recc_default_wideband_decim();
+        if (cfg_v.samples_per_symbol == 0 && (cfg_v.wideband_decim == (uint32_t)CHZ_D || cfg_v.wideband_decim == (uint32_t)CHZ_D768))
+            cfg_v.samples_per_symbol = 1536u / cfg_v.wideband_decim;
+    }
+    const amps_recc_cfg_t *cfg = &cfg_v;
     if (cfg->n_channels < 1 || cfg->max_bursts < 1) return -EINVAL;
     // the channelizer's geometry (M = 1024 at 30.72 Msps) delivers 60 ksps = 3 samples per Manchester symbol at D = 512 and 40 ksps =
     // 2 at D = 768; the bit-domain kernels behind it are built for exactly those.  Two samples per symbol exist on the wideband seam only

@@ -90,6 +90,24 @@ struct ChzArgs {
 constexpr int CHZ_PRE = 4;   // frames of history the carry keeps beyond the filter's own L - D samples: what the exact half of a workgroup's pre-roll reaches back to
 
 typedef float cf2 __attribute__((ext_vector_type(2)));
+// Buffer resource (V#) of the fast loader (round 6).  The fold role's prefetch used `global_load_dwordx2 v, v_off, s[base:base+1]` with
+// a 64-bit scalar base per frame: clamp the frame index to the block, multiply, subtract, shift, add with carry -- nine scalar
+// instructions per frame and two more per chunk, ~65 per half-step in the wave whose instruction count IS the kernel's critical path
+// (a wave issues one instruction per slot, scalar or vector).  A raw buffer load takes a 32-bit scalar byte offset (+ a 12-bit
+// immediate) against ONE descriptor per workgroup, and the hardware's range check (num_records) replaces the clamp: a prefetch that
+// runs past the end of the block returns zeros nobody folds.  One s_add per pair of 2 KB chunks.
+typedef int chz_rsrc_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ chz_rsrc_t chz_make_rsrc(const void *base, uint64_t bytes)
+{
+    const uint64_t a = (uint64_t)base;
+    const uint32_t n = bytes > 0xffffffffull ? 0xffffffffu : (uint32_t)bytes;
+    chz_rsrc_t r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)((a >> 32) & 0xffffu));          // stride 0: a raw buffer, offsets and num_records in bytes
+    r.z = __builtin_amdgcn_readfirstlane((int)n);
+    r.w = 0x00020000;                                                                   // gfx9 family: DATA_FORMAT = 32 (untyped loads ignore it), type = buffer
+    return r;
+}
 
 // Packed fp32 with operand modifiers.  hipcc materialises every swap / negate / broadcast of a packed operand with v_mov /
 // v_xor and keeps broadcast constants as duplicated register PAIRS (the 32 fold coefficients cost 64 VGPRs, the six pass
@@ -387,28 +405,25 @@ __device__ __forceinline__ void chz_fold2_ring(const cf2 (&ring)[4][P + 4], cons
 // The generic path (carry, zero padding: first and last half-steps of a launch) uses ordinary loads and drains them before it
 // returns, so vmcnt(8) is right after either path.
 template <int P, int BASE, int ELEM, int G, bool FAST>
-__device__ __forceinline__ void chz_load1_ring(cf2 (&ring)[4][P + 4], const ChzIn &in, int64_t F, int t)
+__device__ __forceinline__ void chz_load1_ring(cf2 (&ring)[4][P + 4], const ChzIn &in, int64_t F, int t, chz_rsrc_t rsrc = chz_rsrc_t{}, uint32_t soff = 0u)
 {
     constexpr int R = P + 4;
     constexpr int E = (BASE + ELEM + (G >> 1)) % R, J = 2 * (G & 1);
     if constexpr (FAST) {
-        const uint32_t voff = (uint32_t)t * (uint32_t)sizeof(float2);
-        // wave-uniform; clamped to the last whole frame of the block: the prefetch runs two half-steps ahead of the fold and so
-        // up to eight frames past the end of the data -- those loads fetch valid memory nobody folds
-        // (F + G >= 0 on this path: the half-batch in work lies inside the block and the prefetch only runs ahead of it.  The clamp is
-        // done on the FRAME index, in 32 bits, so that it stays on the scalar unit: gfx950 has no 64-bit scalar ordered compare, and
-        // `off > nsamp - D` on 64-bit sample offsets became a v_cmp_lt_i64 per load pair, four per half-step, in the role whose
-        // instructions cost the step most.  f_last = the last frame that lies wholly inside the block.)
-        uint32_t f = (uint32_t)(F + G);
-        f = f < in.f_last ? f : in.f_last;
-        const float2 *q = in.block + ((int64_t)f * CHZ_D - in.lead);
+        // Round 6: raw buffer loads against the workgroup's descriptor (chz_make_rsrc) -- `soff` = byte offset of the half-step in work,
+        // the frame fetched here lies 2 * CHZ_BATCH + G frames behind its first sample; the hardware's range check stands in for the
+        // clamp of rounds 3-5 (frame index against the last whole frame of the block, on the scalar unit since round 5), and the
+        // 64-bit base arithmetic per frame -- ~45 scalar instructions per half-step in the wave that is the kernel's critical path -- is
+        // one s_add.
         // "+v": the destination is TIED to the register that holds the slot's dead value, so the new value is born in the ring's own
         // register -- with "=v" the compiler is free to load into a scratch pair and copy it into place at the next control-flow
         // join, i.e. to READ a register whose load is still in flight (it did: tests/test_cpu_inflight_loads.py scans the
         // assembly for any access to such a register before the wait that covers it)
         // (non-temporal loads change nothing here, 0.380 against 0.381 ms: the kernel is bound by VALU issue, not by its input stream)
-        asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(ring[J][E]) : "v"(voff), "s"(q));
-        asm volatile("global_load_dwordx2 %0, %1, %2 offset:2048" : "+v"(ring[J + 1][E]) : "v"(voff), "s"(q));
+        const uint32_t voff = (uint32_t)t * (uint32_t)sizeof(float2);
+        const uint32_t so = soff + (uint32_t)((2 * CHZ_BATCH + G) * CHZ_D * sizeof(float2));
+        asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(ring[J][E]) : "v"(voff), "s"(rsrc), "s"(so));
+        asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen offset:2048" : "+v"(ring[J + 1][E]) : "v"(voff), "s"(rsrc), "s"(so));
     } else {
         cf2 s0, s1;
         in.template frame<false>(F + G, t, s0, s1);
@@ -517,18 +532,22 @@ __device__ __forceinline__ void chz768_fold2_ring(const cf2 (&ring)[4][CHZ768_R]
 // The sample branch J receives in frame G of the half-step X half-steps behind the one in work (whose first frame is F0, ring rotation
 // BASE): chunk K = (J + G) & 3 of that frame's 768 new samples, into the slot its reception number says.  FAST / generic as at
 // D = 512 (chz_load1_ring): untracked inline-asm loads tied to the slot's own registers, or a bounds-checked load drained at once.
+// FAST: one raw buffer load (chz_make_rsrc).  `soff` = byte offset of the half-step in work inside the workgroup's descriptor; the
+// chunks a half-step fetches are the CONSECUTIVE 2 KB chunks 19 .. 30 behind its own first sample -- the stream is read in order --
+// so chunk c is soff + 2048 (c & ~1) with the odd ones on the 12-bit immediate.
 template <int BASE, int X, int G, int J, bool FAST>
-__device__ __forceinline__ void chz768_load1(cf2 (&ring)[4][CHZ768_R], const ChzIn &in, int64_t F0, int t)
+__device__ __forceinline__ void chz768_load1(cf2 (&ring)[4][CHZ768_R], const ChzIn &in, int64_t F0, int t, chz_rsrc_t rsrc = chz_rsrc_t{}, uint32_t soff = 0u)
 {
     constexpr int K = (J + G) & 3;
     static_assert(K != 3, "branch J receives nothing in frame G");
     constexpr int SLOT = (BASE + 7 + chz768_cnt(J, G) + 3 * X) % CHZ768_R;
     if constexpr (FAST) {
+        constexpr int CH = 3 * (4 * X + G) + K;                      // chunk of 256 samples behind the half-step's first sample
         const uint32_t voff = (uint32_t)t * (uint32_t)sizeof(float2);
-        uint32_t f = (uint32_t)(F0 + 4 * X + G);                      // >= 0 on this path; clamped to the last whole frame of the block (see chz_load1_ring)
-        f = f < in.f_last ? f : in.f_last;
-        const float2 *q = in.block + ((int64_t)f * CHZ_D768 - in.lead) + 256 * K;
-        asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(ring[J][SLOT]) : "v"(voff), "s"(q));
+        const uint32_t so = soff + 2048u * (uint32_t)(CH & ~1);
+        // "+v": the new value is born in the ring's own register (see chz_load1_ring)
+        if constexpr (CH & 1) asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen offset:2048" : "+v"(ring[J][SLOT]) : "v"(voff), "s"(rsrc), "s"(so));
+        else asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(ring[J][SLOT]) : "v"(voff), "s"(rsrc), "s"(so));
     } else {
         cf2 s0 = in.generic((F0 + 4 * X + G) * CHZ_D768 + 256 * K + t);
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(s0) :: "memory");
@@ -575,18 +594,18 @@ __device__ __forceinline__ void chz768_prime(cf2 (&ring)[4][CHZ768_R], const Chz
 }
 // the six loads behind the first tap block of frames 0 / 1, and the six behind that of frames 2 / 3, in the order they are needed
 template <int BASE, bool FAST>
-__device__ __forceinline__ void chz768_loads_a(cf2 (&ring)[4][CHZ768_R], const ChzIn &in, int64_t F0, int t)
+__device__ __forceinline__ void chz768_loads_a(cf2 (&ring)[4][CHZ768_R], const ChzIn &in, int64_t F0, int t, chz_rsrc_t rs, uint32_t so)
 {
-    chz768_load1<BASE, 1, 2, 3, FAST>(ring, in, F0, t); chz768_load1<BASE, 1, 2, 0, FAST>(ring, in, F0, t);
-    chz768_load1<BASE, 1, 3, 1, FAST>(ring, in, F0, t); chz768_load1<BASE, 1, 3, 2, FAST>(ring, in, F0, t);
-    chz768_load1<BASE, 1, 3, 3, FAST>(ring, in, F0, t); chz768_load1<BASE, 2, 0, 0, FAST>(ring, in, F0, t);
+    chz768_load1<BASE, 1, 2, 3, FAST>(ring, in, F0, t, rs, so); chz768_load1<BASE, 1, 2, 0, FAST>(ring, in, F0, t, rs, so);
+    chz768_load1<BASE, 1, 3, 1, FAST>(ring, in, F0, t, rs, so); chz768_load1<BASE, 1, 3, 2, FAST>(ring, in, F0, t, rs, so);
+    chz768_load1<BASE, 1, 3, 3, FAST>(ring, in, F0, t, rs, so); chz768_load1<BASE, 2, 0, 0, FAST>(ring, in, F0, t, rs, so);
 }
 template <int BASE, bool FAST>
-__device__ __forceinline__ void chz768_loads_b(cf2 (&ring)[4][CHZ768_R], const ChzIn &in, int64_t F0, int t)
+__device__ __forceinline__ void chz768_loads_b(cf2 (&ring)[4][CHZ768_R], const ChzIn &in, int64_t F0, int t, chz_rsrc_t rs, uint32_t so)
 {
-    chz768_load1<BASE, 2, 0, 1, FAST>(ring, in, F0, t); chz768_load1<BASE, 2, 0, 2, FAST>(ring, in, F0, t);
-    chz768_load1<BASE, 2, 1, 3, FAST>(ring, in, F0, t); chz768_load1<BASE, 2, 1, 0, FAST>(ring, in, F0, t);
-    chz768_load1<BASE, 2, 1, 1, FAST>(ring, in, F0, t); chz768_load1<BASE, 2, 2, 2, FAST>(ring, in, F0, t);
+    chz768_load1<BASE, 2, 0, 1, FAST>(ring, in, F0, t, rs, so); chz768_load1<BASE, 2, 0, 2, FAST>(ring, in, F0, t, rs, so);
+    chz768_load1<BASE, 2, 1, 3, FAST>(ring, in, F0, t, rs, so); chz768_load1<BASE, 2, 1, 0, FAST>(ring, in, F0, t, rs, so);
+    chz768_load1<BASE, 2, 1, 1, FAST>(ring, in, F0, t, rs, so); chz768_load1<BASE, 2, 2, 2, FAST>(ring, in, F0, t, rs, so);
 }
 // in front of frames 0 / 1: element 8 of every branch and element 9 of branches 0, 1 have arrived (everything but the thirteen
 // youngest loads); in front of frames 2 / 3: element 9 of branches 2, 3 and element 10 of every branch (again thirteen)
@@ -1036,6 +1055,27 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
             }
         }
         chz768_prime(ring, in, fs, t);
+        constexpr int PERIOD = 4;                                 // half-steps until the ring is back where it started (three slots per half-step, twelve slots)
+        // half-step h loads frames of the half-steps h + 1 (from its third frame on) and h + 2: the fast loader is right once the
+        // first frame of half-step h + 1 lies inside the new block
+        // (The unfused form -- a checking mode -- runs every half-step as an edge step at this decimation: with its epilogue's row
+        // addresses the kernel does not fit 168 registers, and what the compiler chose to spill were ring slots with a load in flight
+        // -- it stores the stale value and reloads it behind the wait; tests/test_cpu_inflight_loads.py scans for exactly that.  One
+        // drained batch of twelve loads per half-step is a third of the fast loader's speed, and the arithmetic is the same.)
+        int h_edge = 0;
+        if (IQ || in.nsamp < D) h_edge = nsteps;
+        else if ((fs + NB) * D < in.lead) {
+            const int64_t need = (in.lead + D - 1) / D - (fs + NB);
+            h_edge = (int)((need + NB - 1) / NB);
+            h_edge = (h_edge + PERIOD - 1) / PERIOD * PERIOD;
+            if (h_edge > nsteps) h_edge = nsteps;
+        }
+        // the workgroup's descriptor starts at the first sample of its first FAST half-step (a few frames in front of the block, at the
+        // most, for the workgroup that takes over from the carry: nothing down there is ever addressed); a range beyond 2^31 bytes -- a
+        // 50 GB push -- keeps the bounds-checked loader
+        const int64_t base_s = (fs + (int64_t)NB * h_edge) * D - in.lead;
+        if ((int64_t)(nsteps - h_edge + 3) * NB * D * (int64_t)sizeof(float2) >= (1ll << 31)) h_edge = nsteps;
+        const chz_rsrc_t rsrc = chz_make_rsrc(in.block + base_s, (uint64_t)(in.nsamp - base_s) * sizeof(float2));
         __syncthreads();                                          // all roles start together
         auto half_step = [&](auto basec, auto edgec, int h) {
             constexpr int BASE = decltype(basec)::value;
@@ -1051,9 +1091,10 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
                     chz768_fold2_ring<P, BASE, 2>(ring, coef, tw1, dst, t, [] {});
                     chz768_loads_generic<BASE>(ring, in, F, t);
                 } else {
-                    chz768_fold2_ring<P, BASE, 0>(ring, coef, tw1, dst, t, [&] { chz768_loads_a<BASE, true>(ring, in, F, t); });
+                    const uint32_t so = (uint32_t)(h - h_edge) * (uint32_t)(NB * D * sizeof(float2));   // this half-step inside the workgroup's descriptor
+                    chz768_fold2_ring<P, BASE, 0>(ring, coef, tw1, dst, t, [&] { chz768_loads_a<BASE, true>(ring, in, F, t, rsrc, so); });
                     chz768_ring_wait<BASE, 2>(ring);
-                    chz768_fold2_ring<P, BASE, 2>(ring, coef, tw1, dst, t, [&] { chz768_loads_b<BASE, true>(ring, in, F, t); });
+                    chz768_fold2_ring<P, BASE, 2>(ring, coef, tw1, dst, t, [&] { chz768_loads_b<BASE, true>(ring, in, F, t, rsrc, so); });
                 }
                 CHZ_STAMP(h, 2);
             }
@@ -1061,7 +1102,6 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
             __syncthreads();
             CHZ_STAMP(h, 4);
         };
-        constexpr int PERIOD = 4;                                 // half-steps until the ring is back where it started (three slots per half-step, twelve slots)
         auto run_steps = [&](auto edgec, int hb, int he) __attribute__((always_inline)) {        // half-steps [hb, he); hb is a multiple of the ring's period
             for (int h = hb; h < he; h += PERIOD) {
                 half_step(std::integral_constant<int, 0>{}, edgec, h);
@@ -1073,20 +1113,6 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
                 half_step(std::integral_constant<int, 9>{}, edgec, h + 3);
             }
         };
-        // half-step h loads frames of the half-steps h + 1 (from its third frame on) and h + 2: the fast loader is right once the
-        // first frame of half-step h + 1 lies inside the new block
-        // (The unfused form -- a checking mode -- runs every half-step as an edge step at this decimation: with its epilogue's row
-        // addresses the kernel does not fit 168 registers, and what the compiler chose to spill were ring slots with a load in flight
-        // -- it stores the stale value and reloads it behind the wait; tests/test_cpu_inflight_loads.py scans for exactly that.  One
-        // drained batch of twelve loads per half-step is a third of the fast loader's speed, and the arithmetic is the same.)
-        int h_edge = 0;
-        if (IQ || in.nsamp < D) h_edge = nsteps;
-        else if ((fs + NB) * D < in.lead) {
-            const int64_t need = (in.lead + D - 1) / D - (fs + NB);
-            h_edge = (int)((need + NB - 1) / NB);
-            h_edge = (h_edge + PERIOD - 1) / PERIOD * PERIOD;
-            if (h_edge > nsteps) h_edge = nsteps;
-        }
         run_steps(std::true_type{}, 0, h_edge);
         if constexpr (!IQ) run_steps(std::false_type{}, h_edge, nsteps);
         } else {
@@ -1102,6 +1128,21 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
         }
         chz_load_half_ring<P, 0, P, false>(ring, in, fs, t);
         chz_load_half_ring<P, 0, P + 2, false>(ring, in, fs + NB, t);
+        constexpr int PERIOD = (P + 4) / 2;                       // half-steps until the ring is back where it started (6)
+        static_assert(PERIOD == 6, "the unrolled loop below is written for P = 8");
+        // half-step h loads the frames of half-step h + 2: the fast loader is right once those lie inside the new block
+        int h_edge = 0;
+        if (in.nsamp < D) h_edge = nsteps;
+        else if ((fs + 2 * NB) * D < in.lead) {
+            const int64_t need = (in.lead + D - 1) / D - (fs + 2 * NB);           // frames from the first loaded one to the first inside the block
+            h_edge = (int)((need + NB - 1) / NB);
+            h_edge = (h_edge + PERIOD - 1) / PERIOD * PERIOD;
+            if (h_edge > nsteps) h_edge = nsteps;
+        }
+        // the workgroup's descriptor (chz_make_rsrc) starts at the first sample of its first FAST half-step; a range beyond 2^31 bytes keeps the bounds-checked loader
+        const int64_t base_s = (fs + (int64_t)NB * h_edge) * D - in.lead;
+        if ((int64_t)(nsteps - h_edge + 3) * NB * D * (int64_t)sizeof(float2) >= (1ll << 31)) h_edge = nsteps;
+        const chz_rsrc_t rsrc = chz_make_rsrc(in.block + base_s, (uint64_t)(in.nsamp - base_s) * sizeof(float2));
         __syncthreads();                                          // all roles start together 
         // one half-step = four frames: fold them, then load the frames of the half-step after next into the two slots that
         // just died.  A load has eight frames (~3 us) to arrive: with four frames of lead the fold waves were the critical path
@@ -1129,12 +1170,13 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
                     chz_fold2_ring<P, BASE, 2>(ring, coef, tw1, dst, t, [] {});
                     chz_load_half_ring<P, BASE, P + 4, false>(ring, in, F + 2 * NB, t);
                 } else {
-                    chz_load1_ring<P, BASE, P + 4, 0, true>(ring, in, F + 2 * NB, t);
+                    const uint32_t so = (uint32_t)(h - h_edge) * (uint32_t)(NB * D * sizeof(float2));   // this half-step inside the workgroup's descriptor
+                    chz_load1_ring<P, BASE, P + 4, 0, true>(ring, in, F + 2 * NB, t, rsrc, so);
                     chz_fold2_ring<P, BASE, 0>(ring, coef, tw1, dst, t, [&] {
-                        chz_load1_ring<P, BASE, P + 4, 1, true>(ring, in, F + 2 * NB, t);
-                        chz_load1_ring<P, BASE, P + 4, 2, true>(ring, in, F + 2 * NB, t);
+                        chz_load1_ring<P, BASE, P + 4, 1, true>(ring, in, F + 2 * NB, t, rsrc, so);
+                        chz_load1_ring<P, BASE, P + 4, 2, true>(ring, in, F + 2 * NB, t, rsrc, so);
                     });
-                    chz_fold2_ring<P, BASE, 2>(ring, coef, tw1, dst, t, [&] { chz_load1_ring<P, BASE, P + 4, 3, true>(ring, in, F + 2 * NB, t); });
+                    chz_fold2_ring<P, BASE, 2>(ring, coef, tw1, dst, t, [&] { chz_load1_ring<P, BASE, P + 4, 3, true>(ring, in, F + 2 * NB, t, rsrc, so); });
                 }
                 CHZ_STAMP(h, 2);
             }
@@ -1142,8 +1184,6 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
             __syncthreads();
             CHZ_STAMP(h, 4);
         };
-        constexpr int PERIOD = (P + 4) / 2;                       // half-steps until the ring is back where it started (6)
-        static_assert(PERIOD == 6, "the unrolled loop below is written for P = 8");
         auto run_steps = [&](auto edgec, int hb, int he) __attribute__((always_inline)) {        // half-steps [hb, he); hb is a multiple of the ring's period
             for (int h = hb; h < he; h += PERIOD) {
                 half_step(std::integral_constant<int, 0>{}, edgec, h);
@@ -1159,15 +1199,6 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
                 half_step(std::integral_constant<int, 10>{}, edgec, h + 5);
             }
         };
-        // half-step h loads the frames of half-step h + 2: the fast loader is right once those lie inside the new block
-        int h_edge = 0;
-        if (in.nsamp < D) h_edge = nsteps;
-        else if ((fs + 2 * NB) * D < in.lead) {
-            const int64_t need = (in.lead + D - 1) / D - (fs + 2 * NB);           // frames from the first loaded one to the first inside the block
-            h_edge = (int)((need + NB - 1) / NB);
-            h_edge = (h_edge + PERIOD - 1) / PERIOD * PERIOD;
-            if (h_edge > nsteps) h_edge = nsteps;
-        }
         run_steps(std::true_type{}, 0, h_edge);
         run_steps(std::false_type{}, h_edge, nsteps);
         }

@@ -5,7 +5,7 @@
 //   recctest iqb  <file.fc32> [chunk]  the same through recc_fused's "bursts" port (the 3374-byte blob amps_recc publishes) instead of "records"
 //   recctest bank <file.u8>  [chunk] [C]  C channels in ONE gr::amps::recc_bank block: channel c = the symbol file delayed by 37 c symbols;
 //                                      every line is prefixed with the channel the burst came from
-//   recctest wide <file.fc32> [chunk] [slicer]  one 30.72 Msps wideband capture -> gr::amps::recc_wideband (832 channels from bin 96); every
+//   recctest wide <file.fc32> [chunk] [slicer] [decim]  one 30.72 Msps wideband capture -> gr::amps::recc_wideband (832 channels from bin 96); every
 //                                      burst's lines are prefixed with its channel; decoded through the "bursts" port
 //   recctest widerank <file.fc32> <chunk> <idfile> <nranks> <rank> [mode]   ONE rank of the same band over `nranks` processes (2, 4 or 8; one per GPU of a
 //                                      node): gr::amps::recc_wideband::make(832, 96, -1, nranks, rank) + set_rccl -- rank 0 owns the capture and the
@@ -116,7 +116,7 @@ int main(int argc, char **argv)
             const bool ranks = mode == "widerank";
             if (ranks && argc < 7) { std::fprintf(stderr, "usage: %s widerank <file> <chunk> <idfile> <nranks> <rank> [mode]\n", argv[0]); return 2; }
             const int nranks = ranks ? std::atoi(argv[5]) : 0, rank = ranks ? std::atoi(argv[6]) : 0;
-            auto src = ranks ? gr::amps::recc_wideband::make(832, 96, -1, nranks, rank) : gr::amps::recc_wideband::make(832, 96, argc > 4 ? std::atoi(argv[4]) : -1);
+            auto src = ranks ? gr::amps::recc_wideband::make(832, 96, -1, nranks, rank) : gr::amps::recc_wideband::make(832, 96, argc > 4 ? std::atoi(argv[4]) : -1, 0, 0, argc > 5 ? std::atoi(argv[5]) : 0);
             if (ranks) {
                 // the control plane is the application's: here, a file
                 std::string id;
@@ -151,7 +151,7 @@ int main(int argc, char **argv)
             auto dm = std::make_shared<demux>();
             dm->dec = dec;
             gr::msg_connect(src, "bursts", dm, "bursts");
-            std::vector<char> tail((size_t)64 * 512 * 8, 0);          // silence: flushes the frames the fused form holds back
+            std::vector<char> tail((size_t)64 * 768 * 8, 0);          // silence: flushes the frames the fused form holds back (64 frames of at most 768 samples)
             data.insert(data.end(), tail.begin(), tail.end());
             const size_t ns = data.size() / 8;
             for (size_t off = 0; off < ns; off += (size_t)chunk) {

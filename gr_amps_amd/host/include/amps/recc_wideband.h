@@ -21,7 +21,8 @@ public:
     // groups / group: one band over the GPUs of a node (BASELINE configs[4]).  groups = 2, 4 or 8: this block (one flow graph and one
     //         process per GPU, every one fed the same stream) decodes interleaved channel group `group` only -- cfg.wideband_groups of
     //         include/amps_recc.h; channel numbers on the ports stay whole-band numbers.
-    static sptr make(int n_channels = 832, int first_bin = 96, int slicer = -1, int groups = 0, int group = 0);
+    // decim: input samples per filter-bank frame, 512 (60 ksps per channel) or 768 (40 ksps); 0 = amps_recc_default_wideband_decim()
+    static sptr make(int n_channels = 832, int first_bin = 96, int slicer = -1, int groups = 0, int group = 0, int decim = 0);
     // Let ONE rank own the stream: after this call (a collective over all `nranks` blocks; `id` = the 128 bytes one of them got from
     // rccl_unique_id(), carried between the processes by the application) work() distributes rank `root`'s input over xGMI with RCCL
     // inside amps_recc_push_wideband_dist (mode 0 = flat broadcast, 1 = scatter + all-gather: AMPS_RECC_DIST_*).  The other ranks'

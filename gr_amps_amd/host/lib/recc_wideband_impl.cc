@@ -21,14 +21,14 @@ class recc_wideband_impl : public recc_wideband {
     unsigned long long d_stream_samples = 0, d_paced_items = 0;   // non-root ranks: samples the root has distributed / items this rank's pacing input has offered
 
 public:
-    recc_wideband_impl(int C, int first_bin, int slicer, int groups, int group)
+    recc_wideband_impl(int C, int first_bin, int slicer, int groups, int group, int decim)
         : gr::sync_block("recc_wideband", gr::io_signature::make(1, 1, 2 * sizeof(float)), gr::io_signature::make(0, 0, 0)), d_handle(nullptr),
           d_recs(kMaxRecs), d_bursts((size_t)kMaxRecs * AMPS_RECC_CAPTURE_SYMS)
     {
         amps_recc_cfg_t cfg = {};
         cfg.struct_size = sizeof(cfg);
         cfg.n_channels = (uint32_t)C;
-        cfg.samples_per_symbol = 3;                // 60 ksps per channel behind the channelizer
+        cfg.samples_per_symbol = 0;                // what goes with the decimation: 3 (60 ksps per channel, D = 512) or 2 (40 ksps, D = 768)
         cfg.max_samples_per_push = kMaxPush / 512 + 72;
         cfg.max_bursts = kMaxRecs;
         cfg.device = -1;
@@ -37,7 +37,7 @@ public:
         cfg.wideband_groups = (uint32_t)groups;
         cfg.wideband_group = (uint32_t)group;
         cfg.wideband_channels = 1024;
-        cfg.wideband_decim = 512;
+        cfg.wideband_decim = (uint32_t)decim;     // 0 = amps_recc_default_wideband_decim()
         cfg.wideband_taps_per_branch = 8;
         cfg.wideband_first_channel = (uint32_t)first_bin;
         int rc = amps_recc_create(&d_handle, &cfg);
@@ -115,9 +115,9 @@ public:
     }
 };
 
-recc_wideband::sptr recc_wideband::make(int n_channels, int first_bin, int slicer, int groups, int group)
+recc_wideband::sptr recc_wideband::make(int n_channels, int first_bin, int slicer, int groups, int group, int decim)
 {
-    return gnuradio::get_initial_sptr(new recc_wideband_impl(n_channels, first_bin, slicer, groups, group));
+    return gnuradio::get_initial_sptr(new recc_wideband_impl(n_channels, first_bin, slicer, groups, group, decim));
 }
 
 std::string recc_wideband::rccl_unique_id()

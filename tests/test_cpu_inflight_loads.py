@@ -17,7 +17,8 @@ import pytest
 
 from gr_amps_amd import build
 
-LOAD = re.compile(r"\s*global_load_dwordx2 (v\[\d+:\d+\]), v\d+, s\[")
+# the fast loader's untracked loads: scalar-base global loads (D = 512) or raw buffer loads against the workgroup's descriptor (D = 768)
+LOAD = re.compile(r"\s*(?:global_load_dwordx2|buffer_load_dwordx2) (v\[\d+:\d+\]), v\d+, s\[")
 
 
 def _regs(tok):
@@ -176,7 +177,7 @@ def role_bodies_with_scratch(asm):
             lm = re.match(r"^(\.LBB\d+_\d+):", l)
             if lm:
                 cur = lm.group(1)
-                counts[cur] = {"fma": 0, "add": 0, "align": 0, "scratch": 0, "edge": 0}
+                counts[cur] = {"fma": 0, "add": 0, "align": 0, "scratch": 0, "edge": 0, "tests": 0}
                 continue
             if cur is None:
                 continue
@@ -187,8 +188,12 @@ def role_bodies_with_scratch(asm):
             c["align"] += t.startswith("v_alignbit_b32")
             c["scratch"] += t.startswith("scratch_")
             c["edge"] += bool(re.match(r"global_load_dwordx2 v\[\d+:\d+\], v\[\d+:\d+\], off", t))
-        # (an EDGE half-step of the fold -- bounds-checked loads with 64-bit lane addresses: the head of a launch -- is no steady body)
-        bad += [(m.group(1), b, c) for b, c in counts.items() if c["scratch"] and not c["edge"] and (c["fma"] >= 100 or c["add"] >= 60 or c["align"] >= 20)]
+            c["tests"] += t.startswith("s_cbranch")
+        # (an EDGE half-step of the fold -- bounds-checked loads with 64-bit lane addresses: the head of a launch -- is no steady body, and
+        # neither is a generic time step of the FFT / slicer roles: the five at either end of a workgroup's range test for the rare cases
+        # inside their body, a steady step is straight-line code up to its barrier and the loop's one branch)
+        bad += [(m.group(1), b, c) for b, c in counts.items()
+                if c["scratch"] and not c["edge"] and c["tests"] <= 1 and (c["fma"] >= 100 or c["add"] >= 60 or c["align"] >= 20)]
         i = j
     return bad
 
