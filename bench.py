@@ -376,7 +376,10 @@ def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, w
         # config 3: the whole 832-channel band from one 30.72 Msps stream through the polyphase channelizer
         decim = int(decim or a.decim)
         sps, C, first_bin = 1536 // decim, 832, 96
-        NW = a.samples or (1 << 27)                       # wideband samples per step (1 GiB, 4.4 s of signal)
+        # wideband samples per step: ~1 GiB = 4.4 s of signal, and a whole number of 64-frame groups per CU either way (the filter bank's
+        # workgroups take whole groups of 64 frames: 2^27 samples are 16 groups per CU at D = 512 but 10.67 at D = 768, where eleven
+        # groups per CU are 138 412 032 samples = 1.03 GiB -- a caller who cares picks its push size like that, and so does this step)
+        NW = a.samples or ((1 << 27) if decim == 512 else 11 * 256 * 64 * 768)
         N = NW // decim                                   # samples per channel after the channelizer
         wb = {"channels": 1024, "decim": decim, "taps_per_branch": a.taps, "first_channel": first_bin}
         n_band = C
@@ -650,7 +653,7 @@ def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, w
                                 "fused slicer (numeric spec %s) + sync + BCH(63,51) decode, records drained every step%s"
                                 % (name, C, N, SLICERS[slicer], drain_note)),
                    "channels_per_gpu": C, "samples_per_channel": N, "samples_per_symbol": sps, "slicer_spec": SLICERS[slicer],
-                   **({"wideband_decim": decim} if wide else {}),
+                   **({"wideband_decim": decim, "wideband_samples_per_step": NW} if wide else {}),
                    "algorithmic_bytes_per_symbol": round(alg_bytes / syms_per_step_rank, 2),
                    "realtime_channels_per_gpu": round(value / world / 20e3, 1),
                    **({"records_gathered_at_rank0_in_one_step": gathered} if gathered is not None else {}),
@@ -865,7 +868,7 @@ def main(argv=None):
                 out[key] = {"workload": "wideband832, one band over all ranks (%s)" % label, "value": b["value"], "unit": "Msym/s", "steps": bsteps,
                             "ms_per_step": b["ms_per_step"], "scaling": "strong", "config": b["config"],
                             "collective": dict(b.get("collective") or {}, backend=dist.get_backend(), nranks=dist.get_world_size(),
-                                               bytes_per_step=8 * b["config"]["samples_per_channel"] * b["config"]["wideband_decim"]),
+                                               bytes_per_step=8 * b["config"]["wideband_samples_per_step"]),
                             "kernel_ms_per_rank": [round(float(k), 4) for k in allk.tolist()], "ranks": gather_identities(b.get("identity")),
                             "roofline_rank0": b["roofline"]}
             except Exception as e:                                             # noqa: BLE001 -- recorded, see above

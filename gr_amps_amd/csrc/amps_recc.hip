@@ -507,7 +507,7 @@ extern "C" {
 
 int amps_recc_abi_version(void) { return AMPS_RECC_ABI_VERSION; }
 int amps_recc_default_slicer(void) { return AMPS_SLICER_DEFAULT; }
-uint32_t amps_recc_default_wideband_decim(void) { return (uint32_t)CHZ_D; }
+uint32_t amps_recc_default_wideband_decim(void) { return (uint32_t)CHZ_D768; }
 size_t amps_recc_burst_size(void) { return sizeof(amps_recc_burst_t); }
 
 const char *amps_recc_strerror(int code)

@@ -153,9 +153,9 @@ typedef struct amps_recc_cfg {
     uint32_t flags;                /* AMPS_RECC_FLAG_*                                                    */
     uint32_t wideband_channels;    /* channelizer seam: M branches: 1024 (0 = seam unused); other values: -EINVAL */
     uint32_t wideband_decim;       /* channelizer seam: D input samples per output frame; 0 = amps_recc_default_wideband_decim().
-                                    * 512 (2x oversampled: 60 ksps per channel,
-                                    * samples_per_symbol = 3; the default of every tool here) or 768 (4/3 x oversampled: 40 ksps,
-                                    * samples_per_symbol = 2; 1.5 x fewer frames per input byte)                     */
+                                    * 768 (4/3 x oversampled: 40 ksps per channel, samples_per_symbol = 2; the default since round 6)
+                                    * or 512 (2x oversampled: 60 ksps, samples_per_symbol = 3; 1.5 x the frames per input byte,
+                                    * 0.2 - 0.7 dB more sensitive)                                                     */
     uint32_t wideband_taps_per_branch; /* prototype length = taps_per_branch * M: 8 (0 selects 8)              */
     uint32_t wideband_first_channel;   /* first FFT bin that is an active RECC channel                    */
     uint32_t sync_tolerance;       /* IQ / wideband seams: accept a trigger with up to this many of its 74
@@ -194,9 +194,10 @@ typedef struct amps_recc amps_recc_t; /* opaque; owns device buffers + per-chann
 int         amps_recc_abi_version(void);
 /* the numeric slicer spec (AMPS_SLICER_* of amps_recc_numerics.h) of a handle created with no SLICER flag */
 int         amps_recc_default_slicer(void);
-/* The decimation a wideband handle created with cfg.wideband_decim = 0 uses (and then cfg.samples_per_symbol = 0 is filled in to match:
- * 1536 / decim).  512 = 2x oversampled, 3 samples per symbol: the most sensitive form and the default; 768 = 4/3 x oversampled, 2 samples
- * per symbol: 1.4 x the throughput for ~0.3 dB at 1 % burst loss without a carrier offset and ~1 dB at +-2 kHz. */
+/* The decimation a wideband handle created with cfg.wideband_decim = 0 uses (cfg.samples_per_symbol = 0 is then filled in to match:
+ * 1536 / decim).  768 since round 6: 4/3 x oversampled, 2 samples per symbol -- 1.4 x the throughput of the 2x oversampled bank for
+ * 0.2 dB at 1 % burst loss without a carrier offset and 0.7 dB at +-2 kHz (profiles/r06/decim768_sensitivity.txt).  512 (3 samples per
+ * symbol) stays one field away: the more sensitive form, and what rounds 1-5 shipped. */
 uint32_t    amps_recc_default_wideband_decim(void);
 const char *amps_recc_strerror(int code);
 size_t      amps_recc_burst_size(void);   /* sizeof(amps_recc_burst_t), for binding self-checks */

@@ -23,7 +23,12 @@ def _port():
         return s.getsockname()[1]
 
 
-def _run(extra, n=2, samples=1 << 24, timeout=300):
+# block sizes of these runs: whole groups of 64 frames at either decimation of the filter bank (64 x 1536 samples), so that every step
+# consumes and decodes the same -- 2^24 and 2^23 are no whole number of 768-sample frames
+NS24, NS23 = 170 * 64 * 1536, 85 * 64 * 1536
+
+
+def _run(extra, n=2, samples=NS24, timeout=300):
     import loopccl
     env = dict(os.environ, AMPS_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", AMPS_RECC_RCCL_LIB=loopccl.build(), OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
@@ -57,13 +62,13 @@ def test_two_ranks_whole_bands(gpu):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["dist"] == "bands"
     c = d["config"]
     assert c["channels_per_gpu"] == 832 and c["checked"]["decoded_with_transmitted_MIN"] >= 0.97 * c["checked"]["planted"] > 0
-    assert abs(d["value"] - 2 * 832 * ((1 << 24) / 1536.0) * 3 / (d["ms_per_step"] * 3e-3) * 1e-6) < 1e-3 * d["value"]
+    assert abs(d["value"] - 2 * 832 * (NS24 / 1536.0) * 3 / (d["ms_per_step"] * 3e-3) * 1e-6) < 1e-3 * d["value"]
     # the same invocation also measures what BASELINE configs[4] names: one band, rank 0's block broadcast inside the timed region
     s = d["secondary"]
-    assert s["scaling"] == "strong" and s["collective"]["nranks"] == 2 and s["collective"]["bytes_per_step"] == 8 << 24
+    assert s["scaling"] == "strong" and s["collective"]["nranks"] == 2 and s["collective"]["bytes_per_step"] == 8 * NS24
     assert len(s["kernel_ms_per_rank"]) == 2 and all(k > 0 for k in s["kernel_ms_per_rank"])
     assert s["config"]["channels_per_gpu"] == 416 and s["config"]["checked"]["decoded_with_transmitted_MIN"] >= 0.97 * s["config"]["checked"]["planted"] > 0
-    assert abs(s["value"] - 832 * ((1 << 24) / 1536.0) * s["steps"] / (s["ms_per_step"] * s["steps"] * 1e-3) * 1e-6) < 1e-3 * s["value"]
+    assert abs(s["value"] - 832 * (NS24 / 1536.0) * s["steps"] / (s["ms_per_step"] * s["steps"] * 1e-3) * 1e-6) < 1e-3 * s["value"]
     _check_ranks(d["ranks"], 2, False)
     assert d["distinct_devices"] == 1 and d["process_group"] == {"backend": "gloo", "world_size": 2}     # (one GPU here: an 8-GPU record says 8)
 
@@ -73,7 +78,7 @@ def test_four_and_eight_ranks_under_the_launcher(gpu, n):
     """G = 4 and G = 8 under the launcher, not only in test_gpu_channel_groups.py.  ONE invocation, as the driver's
     scaling run makes it: the headline (a band per rank) + the one band broadcast through torch.distributed + the one band by scatter +
     all-gather issued inside the C ABI -- one JSON line with n per-rank entries."""
-    ns = 1 << 23
+    ns = NS23
     d = _run([], n, ns)
     assert d["n_gpus"] == n and d["scaling"] == "weak" and d["dist"] == "bands" and d["config"]["channels_per_gpu"] == 832
     assert abs(d["value"] - n * 832 * (ns / 1536.0) * 3 / (d["ms_per_step"] * 3e-3) * 1e-6) < 1e-3 * d["value"]
@@ -95,7 +100,7 @@ def test_four_and_eight_ranks_under_the_launcher(gpu, n):
 
 @pytest.mark.parametrize("n,mode", [(8, "scatter_allgather_abi"), (2, "broadcast_abi")])
 def test_one_band_modes_as_the_headline(gpu, n, mode):
-    ns = 1 << 23
+    ns = NS23
     d = _run(["--dist", mode], n, ns)
     assert d["n_gpus"] == n and d["scaling"] == "strong" and d["dist"] == mode
     c = d["config"]
@@ -116,7 +121,7 @@ def test_two_ranks_one_band_by_channel_groups(gpu):
     c = d["config"]
     assert c["channels_per_gpu"] == 416 and "channel groups" in c["parallelism"]
     assert c["checked"]["planted"] > 50 and c["checked"]["decoded_with_transmitted_MIN"] >= 0.97 * c["checked"]["planted"]
-    assert abs(d["value"] - 832 * ((1 << 24) / 1536.0) * 3 / (d["ms_per_step"] * 3e-3) * 1e-6) < 1e-3 * d["value"]
+    assert abs(d["value"] - 832 * (NS24 / 1536.0) * 3 / (d["ms_per_step"] * 3e-3) * 1e-6) < 1e-3 * d["value"]
 
 
 @pytest.mark.parametrize("mode", ["broadcast_abi", "scatter_allgather_abi"])
@@ -125,7 +130,7 @@ def test_one_rank_distribution_inside_the_c_abi(gpu, mode):
     communicator id over torch.distributed's control plane, ncclCommInitRank + ncclBroadcast issued by the library, the records checked"""
     env = dict(os.environ, AMPS_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_port()),
                RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--samples", str(1 << 24),
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--samples", str(NS24),
            "--prewarm-ms", "20", "--no-cpu-baseline", "--no-other-specs", "--secondary", "none", "--dist", mode]
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
