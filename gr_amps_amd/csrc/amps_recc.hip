@@ -232,6 +232,23 @@ int debug_sync(amps_recc *h, const char *what)
     return e == hipSuccess ? 0 : -EIO;
 }
 
+// Waits of the host on the handle's stream.  With a live communicator the handle's kernels may be queued behind a data collective
+// whose peer has died: every such wait is bounded (rccl_wait / rccl_wait_event: on expiry the communicator is aborted, the collective
+// returns and the stream drains) -- ADVICE r05: drain, destroy and reset used to sit in hipStreamSynchronize / hipEventSynchronize.
+int sync_stream(amps_recc *h, hipStream_t s)
+{
+    if (h->rccl.comm && !h->rccl.dead) { if (int rc = rccl_wait(h->rccl, s)) return rc; return 0; }
+    return hipStreamSynchronize(s) == hipSuccess ? 0 : -EIO;
+}
+int sync_event(amps_recc *h, hipEvent_t e)
+{
+    if (h->rccl.comm && !h->rccl.dead) { if (int rc = rccl_wait_event(h->rccl, e)) return rc; return 0; }
+    return hipEventSynchronize(e) == hipSuccess ? 0 : -EIO;
+}
+// A communicator that died under work in flight leaves the stream state advanced over a block that never arrived: everything the
+// handle would report from there on is void.  The data seams and the drains answer -ESTALE until amps_recc_reset.
+#define STALE_CHECK(h) do { if ((h)->rccl.stale) return -ESTALE; } while (0)
+
 void select_record_list(amps_recc *h, int b)
 {
     h->cur_buf = b;
@@ -525,6 +542,7 @@ const char *amps_recc_strerror(int code)
     case EBUSY: return "busy: a split drain is open, the stream has started, or the handle already has a communicator";
     case ETIMEDOUT: return "no answer from the other ranks within the RCCL timeout: communicator aborted";
     case ENOTCONN: return "the handle's communicator has been aborted";
+    case ESTALE: return "the communicator died with collectives in flight: stream state and record lists are void until amps_recc_reset";
     case EREMOTEIO: return "another rank reported an error: no rank ran the collective";
     default: return "unknown error";
     }
@@ -674,7 +692,7 @@ void amps_recc_destroy(amps_recc_t *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->stream) { (void)sync_stream(h, h->stream); (void)hipStreamSynchronize(h->stream); }   // bounded first: a dead peer must not hang the destructor
     collect_spans(h);
     h->stage_iq_fence.destroy();
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
@@ -700,8 +718,11 @@ int amps_recc_reset(amps_recc_t *h)
 {
     if (!h) return -EINVAL;
     HIP_TRY(hipSetDevice(h->device));
+    (void)sync_stream(h, h->stream);          // bounded while a communicator lives (on expiry it is aborted and the stream drains)
     HIP_TRY(hipStreamSynchronize(h->stream));
     collect_spans(h);
+    h->rccl.stale = false;                    // a fresh stream: whatever an aborted collective left behind is gone
+    if (h->open_buf >= 0) { volatile uint32_t *hdr = h->hdr_host + HDR_STRIDE * h->open_buf; hdr[0] = 0u; hdr[1] = 0u; h->open_buf = -1; }
     return reset_state(h);
 }
 
@@ -885,6 +906,7 @@ int run_bits_device(amps_recc *h, uint32_t P)
 int amps_recc_push_wideband(amps_recc_t *h, const float *iq, size_t nsamp, int mem)
 {
     if (!h) return -EINVAL;
+    STALE_CHECK(h);
     if (!h->chz.enabled) return -ENOSYS;
     if (nsamp == 0) return 0;
     if (!iq) return -EINVAL;
@@ -939,6 +961,7 @@ int amps_recc_rccl_set_timeout(amps_recc_t *h, uint32_t milliseconds)
 {
     if (!h || milliseconds == 0) return -EINVAL;
     h->rccl.timeout_ms = milliseconds;
+    h->rccl.timeout_set = true;
     return 0;
 }
 
@@ -960,7 +983,11 @@ int amps_recc_rccl_info(amps_recc_t *h, amps_recc_rccl_info_t *info)
     info->alive = r.comm ? 1 : 0;
     info->nranks = r.nranks; info->rank = r.rank;
     info->comm_nranks = -1; info->comm_rank = -1;
-    RcclApi &api = rccl_api();
+    // (librccl is loaded only for a handle that has, or had, a communicator: a single-GPU caller who asks for the device identity must
+    // not pull a second copy of RCCL into a process that bundles its own -- ADVICE r05)
+    const bool touched = r.comm != nullptr || r.dead;
+    static RcclApi none;
+    RcclApi &api = touched ? rccl_api() : none;
     if (r.comm && api.CommCount) { int v = -1; if (api.CommCount(r.comm, &v) == 0) info->comm_nranks = v; }
     if (r.comm && api.CommUserRank) { int v = -1; if (api.CommUserRank(r.comm, &v) == 0) info->comm_rank = v; }
     info->device = h->device;
@@ -1164,6 +1191,7 @@ int amps_recc_record_event(amps_recc_t *h, void *hip_event)
 int amps_recc_drain_begin(amps_recc_t *h)
 {
     if (!h) return -EINVAL;
+    STALE_CHECK(h);
     if (h->open_buf >= 0) return -EBUSY;
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = h->stream;
@@ -1205,7 +1233,8 @@ static int drain_end_impl(amps_recc_t *h, amps_recc_burst_t *out, uint8_t *burst
     // because one drain failed
     auto fail = [&](int rc) { hdr[0] = 0u; hdr[1] = 0u; h->open_buf = -1; return rc; };
     if (hipSetDevice(h->device) != hipSuccess) return fail(-EIO);
-    if (hipEventSynchronize(h->drain_event) != hipSuccess) return fail(-EIO);   // everything enqueued before drain_begin is done; later pushes may still run
+    if (int wrc = sync_event(h, h->drain_event)) return fail(wrc);   // everything enqueued before drain_begin is done; later pushes may still run (bounded behind a collective)
+    if (h->rccl.stale) return fail(-ESTALE);
     collect_spans(h);
     uint32_t n = hdr[0];
     const uint32_t st = hdr[1];

@@ -101,8 +101,12 @@ struct RcclLocal {
 struct RcclState {
     void *comm = nullptr;
     bool dead = false;                                       // timed out or aborted: every later call answers -ENOTCONN
+    bool stale = false;                                      // the communicator died with collectives in flight: the handle's stream state and record lists are void
+                                                             // until amps_recc_reset (the consumer kernels queued behind an aborted collective run on
+                                                             // a receive buffer that holds the block of two pushes ago, partly overwritten)
     int nranks = 0, rank = 0;
     uint32_t timeout_ms = 30000;
+    bool timeout_set = false;                                // amps_recc_rccl_set_timeout was called: the environment does not override it
     hipStream_t cstream = nullptr;
     float2 *buf[2] = { nullptr, nullptr };
     size_t buf_samples = 0;                                  // allocated per buffer (cap_common + slack for the scatter chunks)
@@ -152,15 +156,23 @@ inline void rccl_kill(RcclState &r)
     else if (r.comm && rccl_api().ok()) (void)rccl_api().CommDestroy(r.comm);
     r.comm = nullptr;
     r.dead = true;
+    r.stale = true;
 }
 
+inline int rccl_wait(RcclState &r, hipStream_t s);
 inline void rccl_destroy(RcclState &r)
 {
-    if (r.cstream && !r.dead) (void)hipStreamSynchronize(r.cstream);
+    // bounded like every other wait on a collective: a peer that died inside the last data collective must not hang the
+    // destructor; on expiry rccl_wait has aborted the communicator, after which the stream drains by itself
+    if (r.cstream && r.comm && !r.dead) (void)rccl_wait(r, r.cstream);
+    if (r.cstream) (void)hipStreamSynchronize(r.cstream);
     if (r.comm && rccl_api().ok()) (void)rccl_api().CommDestroy(r.comm);
     rccl_free_buffers(r);
     if (r.cstream) (void)hipStreamDestroy(r.cstream);
+    const uint32_t keep_ms = r.timeout_ms;
+    const bool keep_set = r.timeout_set, keep_stale = r.stale;
     r = RcclState();
+    r.timeout_ms = keep_ms; r.timeout_set = keep_set; r.stale = keep_stale;   // a failed init leaves a fresh state, not a forgotten bound
 }
 
 // bounded wait of the host for stream s: 0, -EIO, or -ETIMEDOUT with the communicator aborted
@@ -176,6 +188,27 @@ inline int rccl_wait(RcclState &r, hipStream_t s)
             const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
             if ((uint64_t)ms >= r.timeout_ms) {
                 std::fprintf(stderr, "amps_recc: rank %d: no answer from the other ranks within %u ms: communicator aborted\n", r.rank, r.timeout_ms);
+                rccl_kill(r);
+                return -ETIMEDOUT;
+            }
+            usleep(spins > 40000 ? 200 : 20);
+        }
+    }
+}
+
+// the same for an event (a drain's marker on the handle's stream, a timing event on the collective stream)
+inline int rccl_wait_event(RcclState &r, hipEvent_t ev)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0;; spins++) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) return 0;
+        if (e != hipErrorNotReady) { (void)hipGetLastError(); rccl_kill(r); return -EIO; }
+        (void)hipGetLastError();
+        if (spins > 4000) {
+            const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+            if ((uint64_t)ms >= r.timeout_ms) {
+                std::fprintf(stderr, "amps_recc: rank %d: work queued behind a collective did not finish within %u ms: communicator aborted\n", r.rank, r.timeout_ms);
                 rccl_kill(r);
                 return -ETIMEDOUT;
             }
@@ -216,7 +249,8 @@ inline void rccl_harvest(RcclState &r, int slot, bool wait)
     if (!r.t_open[slot]) return;
     if (!wait && hipEventQuery(r.t1[slot]) != hipSuccess) { (void)hipGetLastError(); return; }
     float ms = 0.f;
-    if ((wait ? hipEventSynchronize(r.t1[slot]) : hipSuccess) == hipSuccess && hipEventElapsedTime(&ms, r.t0[slot], r.t1[slot]) == hipSuccess) {
+    if ((wait ? (r.comm && !r.dead ? (rccl_wait_event(r, r.t1[slot]) == 0 ? hipSuccess : hipErrorUnknown) : hipEventSynchronize(r.t1[slot])) : hipSuccess) == hipSuccess &&
+        hipEventElapsedTime(&ms, r.t0[slot], r.t1[slot]) == hipSuccess) {
         r.coll_ms += ms;
         r.coll_count++;
     }
@@ -233,7 +267,7 @@ inline int rccl_init(RcclState &r, const uint8_t *id, int nranks, int rank, cons
     if (!api.ok()) return -ENOSYS;                             // no librccl on this machine
     if (!id || nranks < 1 || rank < 0 || rank >= nranks) return -EINVAL;
     if (r.comm || r.dead) return -EBUSY;
-    if (const char *t = std::getenv("AMPS_RECC_RCCL_TIMEOUT_MS")) { const long v = std::atol(t); if (v > 0) r.timeout_ms = (uint32_t)v; }
+    if (!r.timeout_set) if (const char *t = std::getenv("AMPS_RECC_RCCL_TIMEOUT_MS")) { const long v = std::atol(t); if (v > 0) r.timeout_ms = (uint32_t)v; }
     uint32_t own = 0;
     // a handle built with channel groups decodes 1/groups of the band: the communicator must be exactly those groups, this rank its own
     if (loc.groups >= 2 && ((uint32_t)nranks != loc.groups || (uint32_t)rank != loc.group)) own = EINVAL;

@@ -316,7 +316,12 @@ int amps_recc_debug_demod(amps_recc_t *h, const float *iq, size_t nsamp, int mem
  *    them return an error -- the rank's own, or -EREMOTEIO on the ranks that were fine.  The communicator stays usable;
  *  - every wait of the host is bounded (amps_recc_rccl_set_timeout, default 30 s, or AMPS_RECC_RCCL_TIMEOUT_MS at init): when the
  *    other ranks do not answer the communicator is aborted and the call returns -ETIMEDOUT; from then on the collective entry
- *    points answer -ENOTCONN (the handle itself keeps working: amps_recc_push_wideband, amps_recc_drain ...);
+ *    points answer -ENOTCONN.  Since round 6 the bound holds for EVERY wait that can sit behind a collective -- amps_recc_drain /
+ *    _drain_end / _drain_bursts, amps_recc_reset, amps_recc_rccl_info and amps_recc_destroy as well;
+ *  - an aborted collective lets the kernels queued behind it run on a receive buffer that never received: what the handle found
+ *    since its last drain is void and its stream state has advanced over garbage.  The data seams and the drains therefore answer
+ *    -ESTALE after a communicator died (timeout, error or amps_recc_rccl_abort) until amps_recc_reset has been called; then the handle
+ *    decodes again, on its own (amps_recc_push_wideband) or with a new communicator;
  *  - a rank that has to leave (its flow graph stops, its device failed) calls amps_recc_rccl_abort: its peers then run into their
  *    bound instead of waiting for ever.
  *

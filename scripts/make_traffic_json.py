@@ -20,11 +20,13 @@ def means(sub):
 
 
 out = []
-for key, sub, alg in (("wideband832", "chz12_kernel", 8 << 27), ("direct832", "recc_front_kernel<10", 832 * 262144 * 8)):
+# (the filter bank at its two decimations: D = 768 -- the library default since round 6, the bench's step is 11 * 256 * 64 * 768 samples
+# there -- and D = 512 with its 2^27-sample step; the kernel names end in the decimation)
+for key, sub, alg in (("wideband832", ", 768>(", 8 * 11 * 256 * 64 * 768), ("wideband832", ", 512>(", 8 << 27), ("direct832", "recc_front_kernel<10", 832 * 262144 * 8)):
     m = means(sub)
     if "FETCH_SIZE" not in m or "WRITE_SIZE" not in m:
         continue
-    e = {"key": "%s:%s" % (key, slicer), "kernel_match": sub, "FETCH_SIZE_KB": m["FETCH_SIZE"], "WRITE_SIZE_KB": m["WRITE_SIZE"],
+    e = {"key": "%s:%s%s" % (key, slicer, ":768" if "768" in sub else ""), "kernel_match": sub, "FETCH_SIZE_KB": m["FETCH_SIZE"], "WRITE_SIZE_KB": m["WRITE_SIZE"],
          "correction": "gfx950 FETCH_SIZE reports half of wide coalesced reads (MI355X_MICROARCH.md, HBM): bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024",
          "hbm_bytes_per_launch": 2 * m["FETCH_SIZE"] * 1024 + m["WRITE_SIZE"] * 1024, "algorithmic_bytes_per_launch": alg,
          "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (scripts/profile_round.sh)"}

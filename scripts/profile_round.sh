@@ -14,7 +14,7 @@ rocprofv3 --output-format csv --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LD
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $SHORT > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $SHORT > $OUT/pmc_write.log 2>&1
 find $OUT -type f ! -name "*.csv" ! -name "*.log" -delete
-for k in "chz12_kernel" "recc_front_kernel<10" "recc_bits_kernel" "recc_resolve_kernel" "recc_symbols_kernel"; do echo "== $k"; python $R/scripts/pmc_summary.py $OUT "$k"; done | tee $OUT/pmc_kernels.txt
+for k in ", 768>(" ", 512>(" "recc_front_kernel<10" "recc_bits_kernel<2" "recc_bits_kernel<3" "recc_resolve_kernel<256, 512, true" "recc_resolve_kernel<256, 512, false" "recc_symbols_kernel"; do echo "== $k"; python $R/scripts/pmc_summary.py $OUT "$k"; done | tee $OUT/pmc_kernels.txt
 SLNAME=$SL; if [ "$SL" = "default" ]; then SLNAME=$(cd $R && python -c "from gr_amps_amd import capi; print(capi.SLICER_NAMES[capi.load().amps_recc_default_slicer()])"); fi
 python $R/scripts/make_traffic_json.py $OUT $SLNAME > $OUT/traffic.json
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null

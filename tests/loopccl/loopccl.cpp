@@ -11,6 +11,14 @@
 // the collective has happened), runs the exchange on the host, and returns with the data in place -- a legal, slow implementation of
 // the stream-ordered API.
 //
+// LOOPCCL_ASYNC=1 (the synchronous form above cannot expose a missing or misplaced event between the library's collective
+// stream and the handle's stream -- everything has happened by the time a call returns): a call then only RECORDS an event on its
+// stream, queues the exchange for a worker thread of the communicator and puts a gate (a host function) on the stream; the worker
+// waits for the event -- the work the caller ordered in front of the collective -- runs the exchange with copies of its own and
+// opens the gate.  The call returns at once, the data lands later, in stream order: the real library's contract.  Consumers that do
+// not wait for the library's `filled` event, or a collective that does not wait for `freed` / `root_ready`, now read or overwrite
+// the wrong block.
+//
 // A peer that never comes: a barrier gives up after LOOPCCL_TIMEOUT_MS (default 60 s) and the call returns ncclSystemError -- unless
 // LOOPCCL_ASYNC_HANG_MS is set: then the call behaves like the real thing with a dead peer -- it returns ncclSuccess and leaves a
 // blocked operation on the stream (a host function that sleeps until ncclCommAbort / ncclCommDestroy, or that many milliseconds at
@@ -22,10 +30,15 @@
 #include <unistd.h>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -45,6 +58,7 @@ struct Shm {
 static_assert(std::atomic<uint32_t>::is_always_lock_free, "process-shared atomics");
 
 struct Hang { std::atomic<int> release{0}; long max_ms = 0; };
+struct Job { hipEvent_t ready = nullptr; std::function<int()> run; Hang gate; };
 struct Comm {
     Shm *shm = nullptr;
     int nranks = 0, rank = 0;
@@ -52,6 +66,14 @@ struct Comm {
     std::vector<Pending> pending;
     std::vector<Hang *> hangs;
     bool broken = false;
+    // LOOPCCL_ASYNC: the exchanges run on a worker thread, in issue order
+    bool async = false;
+    int device = 0;
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Job *> jobs;
+    bool quit = false;
 };
 thread_local int g_depth = 0;
 thread_local Comm *g_group_comm = nullptr;
@@ -119,14 +141,14 @@ int transfer(Comm *c, int src, uint32_t dst_mask, const void *from, void *to, si
     return OK;
 }
 
-int run_group(Comm *c, hipStream_t st)
+int run_group(Comm *c, hipStream_t st, bool in_worker = false)
 {
     if (c->pending.size() > MAXOPS) return BAD_USE;
-    if (st && hipStreamSynchronize(st) != hipSuccess) return HIP_ERR;
+    if (!in_worker && st && hipStreamSynchronize(st) != hipSuccess) return HIP_ERR;
     auto &mine = c->shm->table[c->rank];
     mine.n = (uint32_t)c->pending.size();
     for (size_t i = 0; i < c->pending.size(); i++) mine.ops[i] = { c->pending[i].kind, c->pending[i].peer, c->pending[i].bytes };
-    if (barrier(c)) return peer_missing(c, st);
+    if (barrier(c)) return in_worker ? (int)SYS_ERR : peer_missing(c, st);
     int rc = OK;
     for (int s = 0; s < c->nranks && !rc; s++) {
         uint32_t nth[MAXR] = { 0 };                                 // how many sends s -> d have been matched so far
@@ -159,6 +181,41 @@ int run_group(Comm *c, hipStream_t st)
     if (!rc) rc = barrier(c);                                       // the tables may be rewritten from here on
     c->pending.clear();
     return rc;
+}
+
+void worker_main(Comm *c)
+{
+    (void)hipSetDevice(c->device);
+    for (;;) {
+        Job *j = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(c->mu);
+            c->cv.wait(lk, [&] { return c->quit || !c->jobs.empty(); });
+            if (c->jobs.empty()) return;
+            j = c->jobs.front();
+            c->jobs.pop_front();
+        }
+        // everything the caller ordered on the stream in front of the collective has happened
+        const bool ok = hipEventSynchronize(j->ready) == hipSuccess;
+        const int rc = ok ? j->run() : HIP_ERR;
+        (void)hipEventDestroy(j->ready);
+        // a failed exchange (a peer that left) is a collective that never completes: the gate stays shut until the communicator is
+        // aborted or destroyed, or LOOPCCL_ASYNC_HANG_MS have passed -- what rccl_wait has to cope with
+        if (rc == OK) j->gate.release.store(1, std::memory_order_release);
+    }
+}
+// the asynchronous form of a call: event, job, gate
+int submit(Comm *c, hipStream_t st, std::function<int()> fn)
+{
+    Job *j = new Job;                                               // (leaked on purpose, like Hang: the gate's host function may still look at it)
+    j->run = std::move(fn);
+    j->gate.max_ms = env_ms("LOOPCCL_ASYNC_HANG_MS", 20000);
+    if (hipEventCreateWithFlags(&j->ready, hipEventDisableTiming) != hipSuccess || hipEventRecord(j->ready, st) != hipSuccess) return HIP_ERR;
+    c->hangs.push_back(&j->gate);
+    if (hipLaunchHostFunc(st, sleeper, &j->gate) != hipSuccess) return HIP_ERR;
+    { std::lock_guard<std::mutex> lk(c->mu); c->jobs.push_back(j); }
+    c->cv.notify_one();
+    return OK;
 }
 
 } // namespace
@@ -203,6 +260,11 @@ int ncclCommInitRank(void **comm, int nranks, ncclUniqueId id, int rank)
     if (barrier(c)) { munmap(p, sizeof(Shm)); delete c; return SYS_ERR; }
     if (rank == 0) unlink(id.internal);                               // everybody has it mapped: the name can go
     g_only_comm = c;
+    c->async = env_ms("LOOPCCL_ASYNC", 0) != 0;
+    if (c->async) {
+        (void)hipGetDevice(&c->device);
+        c->worker = std::thread(worker_main, c);
+    }
     *comm = c;
     return OK;
 }
@@ -212,6 +274,12 @@ int ncclBroadcast(const void *send, void *recv, size_t count, int dtype, int roo
     Comm *c = (Comm *)comm;
     const size_t bytes = count * dtype_size(dtype);
     if (!c || !bytes || root < 0 || root >= c->nranks) return BAD_ARG;
+    auto body = [=]() -> int {
+        if (barrier(c)) return SYS_ERR;
+        if (c->rank == root && send != recv && hipMemcpy(recv, send, bytes, hipMemcpyDeviceToDevice) != hipSuccess) return HIP_ERR;
+        return transfer(c, root, ~0u, send, recv, bytes);
+    };
+    if (c->async) return submit(c, st, body);
     if (hipStreamSynchronize(st) != hipSuccess) return HIP_ERR;
     if (barrier(c)) return peer_missing(c, st);
     if (c->rank == root && send != recv && hipMemcpy(recv, send, bytes, hipMemcpyDeviceToDevice) != hipSuccess) return HIP_ERR;
@@ -223,6 +291,15 @@ int ncclAllGather(const void *send, void *recv, size_t sendcount, int dtype, voi
     Comm *c = (Comm *)comm;
     const size_t bytes = sendcount * dtype_size(dtype);
     if (!c || !bytes) return BAD_ARG;
+    if (c->async)
+        return submit(c, st, [=]() -> int {
+            if (barrier(c)) return SYS_ERR;
+            char *own = (char *)recv + (size_t)c->rank * bytes;
+            if ((const void *)own != send && hipMemcpy(own, send, bytes, hipMemcpyDeviceToDevice) != hipSuccess) return HIP_ERR;
+            for (int r = 0; r < c->nranks; r++)
+                if (int e = transfer(c, r, ~0u, send, (char *)recv + (size_t)r * bytes, bytes)) return e;
+            return OK;
+        });
     if (hipStreamSynchronize(st) != hipSuccess) return HIP_ERR;
     if (barrier(c)) return peer_missing(c, st);
     char *mine = (char *)recv + (size_t)c->rank * bytes;
@@ -245,6 +322,13 @@ int ncclGroupEnd()
     // take part in the others' exchange -- they wait at the barriers: it belongs to the process's one communicator.
     if (!c) c = g_only_comm;
     if (!c) return OK;
+    if (c->async) {
+        // the posted operations travel with the job (the worker owns c->pending while it runs: jobs are serial); an EMPTY group has no
+        // stream of its own -- the library's scatter posts it on its collective stream like the others, which the test harness names
+        auto ops = std::make_shared<std::vector<Comm::Pending>>(std::move(c->pending));
+        c->pending.clear();
+        return submit(c, st, [c, ops]() -> int { c->pending = *ops; return run_group(c, nullptr, true); });
+    }
     return run_group(c, st);
 }
 static int p2p(uint32_t kind, void *ptr, size_t count, int dtype, int peer, void *comm, hipStream_t st)
@@ -262,12 +346,20 @@ int ncclSend(const void *send, size_t count, int dtype, int peer, void *comm, hi
 int ncclRecv(void *recv, size_t count, int dtype, int peer, void *comm, hipStream_t st) { return p2p(2, recv, count, dtype, peer, comm, st); }
 
 static void release_hangs(Comm *c) { for (Hang *h : c->hangs) h->release.store(1, std::memory_order_release); }
+static void stop_worker(Comm *c)
+{
+    if (!c->async) return;
+    { std::lock_guard<std::mutex> lk(c->mu); c->quit = true; }
+    c->cv.notify_all();
+    if (c->worker.joinable()) c->worker.detach();                  // it may sit in a barrier until that times out or sees the abort flag: not waited for
+}
 int ncclCommAbort(void *comm)
 {
     Comm *c = (Comm *)comm;
     if (!c) return BAD_ARG;
     c->shm->abort_flag.store(1, std::memory_order_release);
     release_hangs(c);
+    stop_worker(c);
     c->broken = true;
     if (g_only_comm == c) g_only_comm = nullptr;
     return OK;                                                       // (the object is leaked on purpose: a sleeper may still look at its Hang)
@@ -277,6 +369,11 @@ int ncclCommDestroy(void *comm)
     Comm *c = (Comm *)comm;
     if (!c) return BAD_ARG;
     release_hangs(c);
+    if (c->async) {                                                  // a clean shutdown: the queue is empty (the library synchronises its stream first)
+        { std::lock_guard<std::mutex> lk(c->mu); c->quit = true; }
+        c->cv.notify_all();
+        if (c->worker.joinable()) c->worker.join();
+    }
     if (g_only_comm == c) g_only_comm = nullptr;
     munmap(c->shm, sizeof(Shm));
     c->shm = nullptr;

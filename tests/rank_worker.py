@@ -120,7 +120,12 @@ def main():
                 out["events"].append(["after_timeout", rc])
                 rc, _ = code_of(r.drain_gather, a.root)
                 out["events"].append(["gather_after_timeout", rc])
-            # the handle itself keeps working without its communicator
+            # what the handle found behind the aborted collective is void: the seams say so until the handle is reset, then it works on
+            rc, _ = code_of(r.drain)
+            out["events"].append(["drain_before_reset", rc])
+            rc, _ = code_of(r.push_wideband, np.zeros(64 * D, np.complex64))
+            out["events"].append(["push_before_reset", rc])
+            r.reset()
             r.drain()
             r.push_wideband(np.zeros(64 * D, np.complex64))
             out["plain_drain_after"] = int(len(r.drain()))

@@ -68,9 +68,14 @@ def _run(stream, tmp_path, nranks, scenario, mode="broadcast", root=0, env_extra
     return [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(nranks)]
 
 
-@pytest.mark.parametrize("nranks,mode,root", [(2, "broadcast", 0), (2, "scatter_allgather", 1), (4, "scatter_allgather", 0), (8, "broadcast", 0), (8, "scatter_allgather", 3)])
-def test_ranks_reproduce_the_whole_band_records(stream, tmp_path, nranks, mode, root):
-    res = _run(stream, tmp_path, nranks, "dist", mode, root)
+@pytest.mark.parametrize("nranks,mode,root,transport", [(2, "broadcast", 0, "sync"), (2, "scatter_allgather", 1, "sync"), (4, "scatter_allgather", 0, "sync"),
+                                                        (8, "broadcast", 0, "sync"), (8, "scatter_allgather", 3, "sync"),
+                                                        (2, "broadcast", 1, "async"), (4, "scatter_allgather", 0, "async"), (8, "scatter_allgather", 3, "async")])
+def test_ranks_reproduce_the_whole_band_records(stream, tmp_path, nranks, mode, root, transport):
+    """transport "async" (LOOPCCL_ASYNC=1, round 6 -- ADVICE r05): the stand-in returns from a collective at once and the data lands
+    later, in stream order, as with the real library; a consumer that did not wait for the library's `filled` event, or a collective
+    that overwrote a receive buffer without waiting for `freed` / `root_ready`, would decode the wrong block here"""
+    res = _run(stream, tmp_path, nranks, "dist", mode, root, env_extra={"LOOPCCL_ASYNC": "1"} if transport == "async" else None)
     n = stream["n"]
     want_pushed = [2000000, 3000064, n - 5000064, 64 * D, 100]
     for r, o in enumerate(res):
@@ -119,7 +124,8 @@ def test_a_handle_built_for_another_group_fails_the_init_on_every_rank(stream, t
 def test_a_rank_that_leaves_does_not_hang_its_peers(stream, tmp_path):
     """the last rank aborts its communicator after the first push; the others' next collective never completes (the stand-in leaves
     a blocked operation on the stream, as a collective kernel without its peer would be): the bounded wait ends it with -ETIMEDOUT
-    after ~1.5 s, later calls answer -ENOTCONN at once, and the handle keeps decoding on its own"""
+    after ~1.5 s, later calls answer -ENOTCONN at once; what the handle found behind the aborted collective is void (-ESTALE from the
+    drains and the data seams: ADVICE r05) until amps_recc_reset, after which it decodes on its own"""
     res = _run(stream, tmp_path, 4, "peer_leaves", "broadcast", 0, env_extra={"LOOPCCL_ASYNC_HANG_MS": "20000", "LOOPCCL_TIMEOUT_MS": "300"})
     for r, o in enumerate(res):
         ev = {e[0]: e[1:] for e in o["events"]}
@@ -130,5 +136,6 @@ def test_a_rank_that_leaves_does_not_hang_its_peers(stream, tmp_path):
             rc, secs = ev["peer_gone"]
             assert rc == -errno.ETIMEDOUT and 1.0 < secs < 10.0, ev
             assert ev["after_timeout"] == [-errno.ENOTCONN] and ev["gather_after_timeout"] == [-errno.ENOTCONN]
+        assert ev["drain_before_reset"] == [-errno.ESTALE] and ev["push_before_reset"] == [-errno.ESTALE]
         assert o["info_after"]["alive"] == 0
         assert o["plain_drain_after"] == 0
