@@ -124,19 +124,22 @@ def test_two_ranks_one_band_by_channel_groups(gpu):
     assert abs(d["value"] - 832 * (NS24 / 1536.0) * 3 / (d["ms_per_step"] * 3e-3) * 1e-6) < 1e-3 * d["value"]
 
 
-@pytest.mark.parametrize("mode", ["broadcast_abi", "scatter_allgather_abi"])
-def test_one_rank_distribution_inside_the_c_abi(gpu, mode):
+@pytest.mark.parametrize("mode,in_place", [("broadcast_abi", False), ("scatter_allgather_abi", False), ("broadcast_abi", True)])
+def test_one_rank_distribution_inside_the_c_abi(gpu, mode, in_place):
     """--dist broadcast_abi / scatter_allgather_abi with a world of one rank (AMPS_BENCH_FORCE_DIST=1: real RCCL, which refuses two ranks on one device): the
     communicator id over torch.distributed's control plane, ncclCommInitRank + ncclBroadcast issued by the library, the records checked"""
+    # (AMPS_RECC_RCCL_FORCE_COLLECTIVE: a one-rank communicator uses a device block in place since round 6 -- here the data collective
+    # itself is the point)
     env = dict(os.environ, AMPS_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_port()),
-               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", AMPS_RECC_RCCL_FORCE_COLLECTIVE="0" if in_place else "1")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--samples", str(NS24),
            "--prewarm-ms", "20", "--no-cpu-baseline", "--no-other-specs", "--secondary", "none", "--dist", mode]
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert d["dist"] == mode and d["n_gpus"] == 1
-    assert d["ranks"][0]["rccl_nranks"] == 1 and "rccl" in d["ranks"][0]["rccl_library"] and d["collective"]["gbps"] > 0       # the REAL librccl
+    assert d["ranks"][0]["rccl_nranks"] == 1 and "rccl" in d["ranks"][0]["rccl_library"]       # the REAL librccl
+    assert (d["collective"]["timed"] == 0) if in_place else (d["collective"]["gbps"] > 0)          # in place: the header exchange alone, no data collective
     c = d["config"]
     assert c["channels_per_gpu"] == 832 and c["checked"]["decoded_with_transmitted_MIN"] >= 0.97 * c["checked"]["planted"] > 0
     # one more step drained through amps_recc_drain_gather (the ranks' lists merged at rank 0 by RCCL)

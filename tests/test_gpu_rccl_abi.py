@@ -2,8 +2,14 @@
 flow graph uses to run one band over the GPUs of a node.  A box has one GPU, so the communicator has ONE rank here (RCCL refuses two
 ranks on a device): ncclCommInitRank, ncclBroadcast into the two receive buffers, the event ordering against the handle's
 stream and the push behind it all run; the records must be those of a plain amps_recc_push_wideband of the same stream."""
+import os
+
 import numpy as np
 import pytest
+
+# a one-rank communicator uses a device-resident block in place since round 6 (no 1 GiB copy per push); this file is about the real
+# librccl's data collectives, so they are forced on (read once by the library, at its first distributed push)
+os.environ["AMPS_RECC_RCCL_FORCE_COLLECTIVE"] = "1"
 
 from gr_amps_amd import capi, synth_wideband as sw
 
