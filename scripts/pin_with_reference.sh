@@ -30,4 +30,5 @@ export LD_LIBRARY_PATH="$PREFIX/lib:$PREFIX/lib64:${LD_LIBRARY_PATH:-}"
 cd "$HERE"
 [ -f tests/golden/pin_inputs.npz ] || python3 scripts/pin/make_pin_inputs.py
 $PY scripts/pin/run_reference.py
+# (tests/golden/pin_manifest.json says what a good file looks like: arrays, dtype kinds, shapes, GNU Radio 3.7 -- the test checks it first)
 python3 -m pytest tests/test_cpu_reference_pins.py -q -rs

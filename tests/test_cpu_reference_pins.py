@@ -71,11 +71,56 @@ def test_the_recipes_inputs_and_the_oracles_side_of_it(sides):
     assert 6000 < orc["orc_g4_out"].size < 7000 and set(np.unique(orc["orc_g4_out"])) <= {0, 1}
 
 
+MANIFEST = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pin_manifest.json")
+
+
+def check_against_manifest(get, keys, prefix):
+    """every array of the manifest is there (under `prefix` instead of 'ref_'), of an accepted dtype kind and of the expected shape"""
+    import json
+    man = json.load(open(MANIFEST))
+    problems = []
+    for name, spec in man["arrays"].items():
+        key = prefix + name[len("ref_"):]
+        if key not in keys:
+            problems.append("missing " + key)
+            continue
+        a = np.asarray(get(key))
+        if a.dtype.kind not in spec["kind"]:
+            problems.append("%s: dtype %s, expected kind %s" % (key, a.dtype, spec["kind"]))
+        want = spec["shape"]
+        ok = list(a.shape) == want if spec["exact_shape"] else (list(a.shape[:-1]) == want[:-1] and abs(a.shape[-1] - want[-1]) <= spec.get("tolerance", 0))
+        if not ok:
+            problems.append("%s: shape %s, expected %s%s" % (key, list(a.shape), want, "" if spec["exact_shape"] else " +- %d" % spec.get("tolerance", 0)))
+    return man, problems
+
+
+def test_the_oracles_side_has_the_manifests_shape(sides):
+    """tests/golden/pin_manifest.json (scripts/pin/make_manifest.py) says what a good reference_pins.npz looks like; the oracle's side of
+    the recipe must have exactly that shape -- so the manifest cannot rot, and whoever runs scripts/pin_with_reference.sh can tell a bad
+    run (wrong GNU Radio, truncated output, a block that published nothing) from a real difference"""
+    import json
+    inp, orc = sides
+    man = json.load(open(MANIFEST))
+    assert {k: {"dtype": str(inp[k].dtype), "shape": list(inp[k].shape)} for k in sorted(inp.files)} == man["inputs"]
+    flat = dict(orc)
+    flat["orc_burst_lines"] = np.array([l for ls in orc["orc_burst_lines"] for l in ls])
+    flat["orc_burst_line_owner"] = np.array([i for i, ls in enumerate(orc["orc_burst_lines"]) for _ in ls], np.int64)
+    flat["orc_g3_out"] = np.zeros(orc["orc_g4_out"].size, np.float32)                 # (the oracle keeps only the sliced symbols)
+    for key in [k for k in inp.files if k.startswith("sym_")]:
+        flat["orc_" + key + "_count"] = np.array([len(orc["orc_" + key + "_bursts"])])
+    _, problems = check_against_manifest(lambda k: flat[k], set(flat), "orc_")
+    assert not problems, problems
+
+
 @pytest.mark.skipif(not os.path.exists(REFERENCE), reason="tests/golden/reference_pins.npz does not exist: the reference cannot be built in this image "
                     "(scripts/pin_with_reference.sh is the recipe for a machine with GNU Radio 3.7 + IT++) -- parity stays 'partial'")
 def test_oracle_equals_the_reference_on_the_pin_inputs(sides):
     inp, orc = sides
     ref = np.load(REFERENCE)
+    # first: is this a good file at all?  (GNU Radio 3.7, every array there, shapes as the committed inputs imply)
+    man, problems = check_against_manifest(lambda k: ref[k], set(ref.files), "ref_")
+    assert str(ref["gnuradio_version"]).startswith(man["gnuradio_version_prefix"]), "built against GNU Radio %s: the restated blocks are 3.7's" % ref["gnuradio_version"]
+    assert not problems, problems
     # R1 / R2: the very blobs, in order
     for key in [k for k in inp.files if k.startswith("sym_")]:
         assert ref["ref_" + key + "_bursts"].tobytes() == orc["orc_" + key + "_bursts"].tobytes(), key
