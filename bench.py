@@ -245,10 +245,13 @@ def cpu_baseline(iq_base, sps, budget_s):
     }
 
 
-# what the 4/3 x oversampled bank costs in sensitivity against the default one (filled in from profiles/r06/decim768_sensitivity.txt)
-DECIM_SENSITIVITY = {"unit": "dB C/N in 30 kHz at 1 % burst loss, wideband seam, slicer spec D",
-                     "source": "profiles/r06/decim768_sensitivity.txt",
-                     "no_offset": {"D512": None, "D768": None}, "carrier_2kHz_clock_100ppm": {"D512": None, "D768": None}}
+# what the 4/3 x oversampled bank (D = 768, the library default since round 6) costs in sensitivity against the 2x oversampled one, on the
+# same blocks: scripts/decim_sensitivity.py on one MI355X, 1248 bursts per point (profiles/r06/decim768_sensitivity.txt)
+DECIM_SENSITIVITY = {"unit": "dB C/N in 30 kHz at 1 % burst loss, wideband seam, slicer spec D, tracked capture",
+                     "source": "profiles/r06/decim768_sensitivity.txt (1248 bursts per point, the same blocks through both decimations)",
+                     "no_offset": {"D512": 9.07, "D768": 9.23}, "clock_100ppm": {"D512": 9.18, "D768": 9.40},
+                     "clock_100ppm_carrier_2kHz": {"D512": 11.57, "D768": 12.29}, "clock_500ppm": {"D512": 9.06, "D768": 9.42},
+                     "penalty_of_D768_dB": {"no_offset": 0.16, "clock_100ppm": 0.22, "clock_100ppm_carrier_2kHz": 0.72, "clock_500ppm": 0.36}}
 
 
 # ----------------------------------------------------------------------------------------------------- flop / byte models
