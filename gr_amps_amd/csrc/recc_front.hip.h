@@ -34,6 +34,7 @@
 //     ring that the capture/decode kernel reads, plus 8 bytes per trigger hit.
 // No MFMA: there is no dense contraction on this path; it is HBM-bound.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "amps_recc.h"
@@ -578,20 +579,25 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? AMPS_FRONT_D2_BL
                 // spec D: three sign bits per sample (Im x, Im(x conj(x[n-1])), Im(x conj(x[n-SPS]))) into three bit rings shaped
                 // like s_g; the slicer bits of the lane's eight samples then come out of a 32-sample window of those rings
                 uint32_t ax = 0u, at = 0u, ac = 0u;                  // sign bits, newest at bit 0
+                // (round 6: the debug taps are tested ONCE per tile, not once per sample -- eight wave-uniform branches sat between the
+                // eight samples' products and fenced the scheduler; the tapped tile runs its own copy of the loop)
+                auto samples = [&](auto tapc) {
 #pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const f2 x = v[SPS + q], p1 = v[SPS + q - 1], ps = v[q];
-                    const float it = __builtin_fmaf(x.y, p1.x, -(x.x * p1.y));
-                    const float ic = __builtin_fmaf(x.y, ps.x, -(x.x * ps.y));
-                    ax = __builtin_amdgcn_alignbit(ax, __float_as_uint(x.y), 31);
-                    at = __builtin_amdgcn_alignbit(at, __float_as_uint(it), 31);
-                    ac = __builtin_amdgcn_alignbit(ac, __float_as_uint(ic), 31);
-                    if (dbg) {
-                        int l8 = 8 * lane; asm volatile("" : "+v"(l8));   /* opaque: the debug tap's lane address is not a kernel-wide invariant worth a spilled register pair */
-                        int64_t rel = t0 + l8 + q;
-                        if (rel < (int64_t)a.P) { a.dbg_d[rel] = it; a.dbg_S[rel] = ic; }
+                    for (int q = 0; q < 8; q++) {
+                        const f2 x = v[SPS + q], p1 = v[SPS + q - 1], ps = v[q];
+                        const float it = __builtin_fmaf(x.y, p1.x, -(x.x * p1.y));
+                        const float ic = __builtin_fmaf(x.y, ps.x, -(x.x * ps.y));
+                        ax = __builtin_amdgcn_alignbit(ax, __float_as_uint(x.y), 31);
+                        at = __builtin_amdgcn_alignbit(at, __float_as_uint(it), 31);
+                        ac = __builtin_amdgcn_alignbit(ac, __float_as_uint(ic), 31);
+                        if constexpr (decltype(tapc)::value) {
+                            int l8 = 8 * lane; asm volatile("" : "+v"(l8));   /* opaque: the debug tap's lane address is not a kernel-wide invariant worth a spilled register pair */
+                            int64_t rel = t0 + l8 + q;
+                            if (rel < (int64_t)a.P) { a.dbg_d[rel] = it; a.dbg_S[rel] = ic; }
+                        }
                     }
-                }
+                };
+                if (__builtin_expect(dbg, 0)) samples(std::true_type{}); else samples(std::false_type{});
                 uint8_t *const bx = (uint8_t *)s_x, *const bt = (uint8_t *)(s_x + (GW32 + 2)), *const bc = (uint8_t *)(s_x + 2 * (GW32 + 2));
                 const int bo = slot * (TILE / 8) + lane;
                 const uint8_t vx = (uint8_t)(__builtin_bitreverse32(ax) >> 24), vt = (uint8_t)(__builtin_bitreverse32(at) >> 24),

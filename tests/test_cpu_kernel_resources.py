@@ -48,9 +48,12 @@ def test_streaming_kernel_budget(res):
             assert r["lds_bytes"] <= 40 * 1024, (name, r)              # four workgroups per CU
     # the instantiations a handle takes by default at the bench's sample rate (depth 1; spec D = the default, spec A) spill nothing
     # at all since round 4 (the rare paths' lane addresses are no longer hoisted into kernel-wide invariants)
-    for sl in (0, 3):
+    # (round 6: spec D tests for its debug taps once per tile instead of once per sample -- -1.5 % kernel time -- and the second copy of
+    # its sample loop costs one 64-bit segment invariant its register: stored in the kernel's set-up, reloaded once per SEGMENT, never in
+    # the tile loop)
+    for sl, spill_ok in ((0, 0), (3, 2)):
         for name, r in _one(res, "void amps::recc_front_kernel<10, 1, false, false, %d>" % sl).items():
-            assert r["vgpr_spill"] == 0 and r["scratch_bytes_per_lane"] == 0, (name, r)
+            assert r["vgpr_spill"] <= spill_ok and r["scratch_bytes_per_lane"] <= 8 * spill_ok, (name, r)
 
 
 def test_small_kernels_fit_many_per_cu(res):
