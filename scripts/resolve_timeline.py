@@ -16,10 +16,11 @@ from gr_amps_amd import capi
 
 every = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 dev = torch.device("cuda:0")
-NW = 1 << 27
+decim = int(os.environ.get("CHZ_DECIM", "768"))
+NW = (1 << 27) if decim == 512 else 11 * 256 * 64 * 768
 x, planted = bench.make_wideband_batch(torch, dev, NW, 96, 832, every, seed=3)
-with capi.Recc(n_channels=832, sps=3, max_samples=NW // 512 + 8, max_bursts=8192, sync_torch=False,
-               wideband={"channels": 1024, "decim": 512, "taps_per_branch": 8, "first_channel": 96}) as r:
+with capi.Recc(n_channels=832, sps=1536 // decim, max_samples=NW // decim + 72, max_bursts=8192, sync_torch=False,
+               wideband={"channels": 1024, "decim": decim, "taps_per_branch": 8, "first_channel": 96}) as r:
     torch.cuda.synchronize()
     for _ in range(4):
         r.push_wideband(x)
