@@ -412,7 +412,17 @@ void front_housekeeping_args(amps_recc *h, FrontArgs &fa)
 
 // the fused chain on channel-major device IQ: front -> carry -> resolve -> capture/decode
 // one workgroup per channel; wide groups when a channel spans more wave segments than 256 lanes cover in one batch
-static void launch_resolve(amps_recc *h, ResolveArgs &ra, hipStream_t s)
+// AMPS_RECC_BITS_KERNEL=separate: the wideband seam's trigger search as its own launch (recc_bits_kernel, rounds 2-5) instead of the
+// search stage inside the resolve kernel -- an independent launch structure the GPU suite checks the default against
+static bool bits_search_is_separate()
+{
+    static const bool v = [] { const char *e = std::getenv("AMPS_RECC_BITS_KERNEL"); return e && std::strcmp(e, "separate") == 0; }();
+    return v;
+}
+// the search stage inside the resolve kernel serves the many-channel form (no capture queue) at the wideband seam's two rates
+static bool search_in_resolve(const amps_recc *h) { return h->chz.enabled && !h->capq && !bits_kernel_is_front() && !bits_search_is_separate() && (h->sps == 2 || h->sps == 3); }
+
+static void launch_resolve(amps_recc *h, ResolveArgs &ra, hipStream_t s, bool search = false)
 {
     // capture + decode side of the kernel
     ra.gring = h->gring; ra.ring_mask = h->ring_words - 1; ra.ring_words = h->ring_words; ra.cap_words = resolve_cap_words(h->sps);
@@ -440,6 +450,15 @@ static void launch_resolve(amps_recc *h, ResolveArgs &ra, hipStream_t s)
     if (wide) {
         if (two) hipLaunchKernelGGL((recc_resolve_kernel<RESOLVE_THREADS_WIDE, RESOLVE_LDS_HITS_WIDE, true>), dim3(h->C), dim3(RESOLVE_THREADS_WIDE), lds, s, ra);
         else hipLaunchKernelGGL((recc_resolve_kernel<RESOLVE_THREADS_WIDE, RESOLVE_LDS_HITS_WIDE, false>), dim3(h->C), dim3(RESOLVE_THREADS_WIDE), lds, s, ra);
+    } else if (search) {
+        const dim3 g(h->C), b(RESOLVE_THREADS);
+        if (two) {
+            if (ra.search_tol) hipLaunchKernelGGL((recc_resolve_kernel<RESOLVE_THREADS, RESOLVE_LDS_HITS, true, 2, true>), g, b, lds, s, ra);
+            else hipLaunchKernelGGL((recc_resolve_kernel<RESOLVE_THREADS, RESOLVE_LDS_HITS, true, 2, false>), g, b, lds, s, ra);
+        } else {
+            if (ra.search_tol) hipLaunchKernelGGL((recc_resolve_kernel<RESOLVE_THREADS, RESOLVE_LDS_HITS, false, 3, true>), g, b, lds, s, ra);
+            else hipLaunchKernelGGL((recc_resolve_kernel<RESOLVE_THREADS, RESOLVE_LDS_HITS, false, 3, false>), g, b, lds, s, ra);
+        }
     } else {
         if (two) hipLaunchKernelGGL((recc_resolve_kernel<RESOLVE_THREADS, RESOLVE_LDS_HITS, true>), dim3(h->C), dim3(RESOLVE_THREADS), lds, s, ra);
         else hipLaunchKernelGGL((recc_resolve_kernel<RESOLVE_THREADS, RESOLVE_LDS_HITS, false>), dim3(h->C), dim3(RESOLVE_THREADS), lds, s, ra);
@@ -861,6 +880,23 @@ int run_bits_device(amps_recc *h, uint32_t P)
     uint32_t nwaves = (uint32_t)std::min<uint64_t>(h->max_waves_bits, (G + MIN_SPAN - 1) / MIN_SPAN);
     if (nwaves == 0) nwaves = 1;
     const uint32_t span = (uint32_t)((G + nwaves - 1) / nwaves);
+    if (search_in_resolve(h)) {
+        // round 6: ONE launch -- every channel's workgroup searches its own slicer bits (a quarter of the push per wave, hits in LDS),
+        // then resolves, captures and decodes them as ever; the launch's housekeeping goes with it
+        FrontArgs hk{};
+        front_housekeeping_args(h, hk);
+        ResolveArgs ra{};
+        ra.tiles_per_channel = Tc; ra.span = span; ra.sps = h->sps; ra.n_proc = h->n_done + P;
+        ra.next_allowed = h->next_allowed; ra.pending = h->pending;
+        ra.search_P = P; ra.search_tol = h->cfg.sync_tolerance; ra.zero1 = hk.zero1; ra.zero2 = hk.zero2;
+        {
+            SpanGuard g(h, T_RESOLVE);
+            launch_resolve(h, ra, s, true);
+        }
+        HIP_TRY(hipGetLastError());
+        h->n_done += P;
+        return 0;
+    }
     if ((uint64_t)(Tc + span - 1) / span + 1 > h->max_chunks) return -E2BIG;
     FrontArgs fa{};
     fa.r_prev = 0; fa.avail = P; fa.P = P; fa.tiles_per_channel = Tc; fa.n_channels = h->C; fa.span = span;

@@ -90,12 +90,13 @@ __device__ __noinline__ uint32_t bits_emit_block(int64_t dblk, uint32_t m0, uint
 __device__ unsigned long long bits_tl[3 * 16384];     // per wave: s_memtime at entry and exit, XCC id (scripts/bits_timeline.py)
 #endif
 
-template <int SPS, bool TOL = false>
-__global__ __launch_bounds__(256) void recc_bits_kernel(FrontArgs a)
+// One segment of one channel's bit stream: the run starts located in [512 t_lo - 64, min(512 t_hi, P) - 64) (relative to n_done), appended
+// in stream order to dst (det_cap entries; more set bit 0 of *status); returns their number.  One wave; s_w = its window of KP + 256
+// dwords.  Shared by the stand-alone kernel below and by the search stage inside the resolve kernel (recc_resolve.hip.h, round 6).
+template <int SPS, bool TOL>
+__device__ __forceinline__ uint32_t bits_search_segment(const uint64_t *gring_c, uint32_t ring_words, uint64_t n_done, uint32_t P, uint32_t tol, uint32_t *status,
+                                                        uint32_t t_lo, uint32_t t_hi, uint32_t *s_w, uint64_t *dst, uint32_t det_cap, int lane)
 {
-#ifdef BITS_TIMELINE
-    const unsigned long long tl_t0 = __builtin_amdgcn_s_memtime();
-#endif
     constexpr int D = AMPS_DEDUP_SYMBOLS * SPS;          // dedup / run window in samples
     constexpr int HIST = SPS * (TRIG - 1);               // a match at n looks back to n - HIST
     constexpr int K = (HIST + 31) / 32;                  // history dwords a lane needs besides its own
@@ -103,49 +104,29 @@ __global__ __launch_bounds__(256) void recc_bits_kernel(FrontArgs a)
     constexpr int JW = 4;                                // dwords a lane owns in a block
     constexpr int U = 2;                                 // blocks in flight per wave
     static_assert(D <= 32 && K <= KP - 1, "bit-domain kernel is for small samples-per-symbol");
-    // window of one wave: [KP - h] = the h-th dword before the block (h = 1..K), [KP + q] = dword q of the block
-    __shared__ __attribute__((aligned(16))) uint32_t s_w_all[4][KP + 64 * JW];
-    front_housekeeping(a);
-
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    uint32_t *s_w = s_w_all[wv];
-    const uint32_t w_id = blockIdx.x * 4 + wv;
-    const uint64_t Tc = a.tiles_per_channel;
-    const uint64_t g_end_all = (uint64_t)a.n_channels * Tc;
-    uint64_t g0 = (uint64_t)w_id * a.span;
-    uint64_t g1 = g0 + a.span; if (g1 > g_end_all) g1 = g_end_all;
-
-    while (g0 < g1) {                                    // one segment = a run of tiles inside one channel
-        const int c = (int)(g0 / Tc);
-        const uint32_t t_lo = (uint32_t)(g0 - (uint64_t)c * Tc);
-        uint32_t t_hi = t_lo + (uint32_t)(g1 - g0); if (t_hi > Tc) t_hi = (uint32_t)Tc;
-        const uint32_t chunk = w_id - (uint32_t)(((uint64_t)c * Tc) / a.span);   // k-th segment of this channel
-        g0 += (uint64_t)(t_hi - t_lo);
-        const uint32_t *gring32 = (const uint32_t *)(a.gring + (uint64_t)c * a.ring_words);
-        uint64_t *dst = a.det + ((uint64_t)c * a.max_chunks + chunk) * a.det_cap;
-        uint32_t ndet = 0;                               // wave-uniform
-
+    const uint32_t *gring32 = (const uint32_t *)gring_c;
+    uint32_t ndet = 0;                                   // wave-uniform
+    {
         // run starts of this segment: relative sample positions [E0, E1)
         int64_t E0 = (int64_t)t_lo * TILE - 64;
-        int64_t E1 = (int64_t)t_hi * TILE; if (E1 > (int64_t)a.P) E1 = a.P;
+        int64_t E1 = (int64_t)t_hi * TILE; if (E1 > (int64_t)P) E1 = P;
         E1 -= 64;
-        if ((int64_t)a.n_done + E0 < 0) E0 = -(int64_t)a.n_done;      // nothing before the stream
+        if ((int64_t)n_done + E0 < 0) E0 = -(int64_t)n_done;      // nothing before the stream
         if (E1 > E0) {
             // matches are needed on [E0 - D, E1 + D); dwords [d_first, d_last) of the relative bit stream.  d_first is moved down
             // to a ring index that is a multiple of four (16-byte loads; the stream position is a multiple of 64 and the ring a
             // power of two, so the ring index is 32-bit arithmetic)
             const int64_t M0 = E0 - D, M1 = E1 + D;
-            const uint32_t mask32 = 2u * a.ring_words - 1u;
-            const uint32_t base32 = (uint32_t)(a.n_done >> 5) & mask32;
+            const uint32_t mask32 = 2u * ring_words - 1u;
+            const uint32_t base32 = (uint32_t)(n_done >> 5) & mask32;
             int64_t d_first = M0 >= 0 ? M0 / 32 : -((-M0 + 31) / 32);
             d_first -= (int64_t)((base32 + (uint32_t)d_first) & (uint32_t)(JW - 1));
             const int64_t d_last = (M1 + 31) / 32;
             const int ndw = (int)(d_last - d_first);
             const int nwide = (ndw + 64 * JW - 1) / (64 * JW);                  // blocks (the last one may reach past d_last: its surplus positions lie outside [E0, E1))
-            const bool pre = (int64_t)a.n_done + 32 * (d_first - K) < 0;        // wave-uniform: the segment reaches before the stream (ones there)
+            const bool pre = (int64_t)n_done + 32 * (d_first - K) < 0;        // wave-uniform: the segment reaches before the stream (ones there)
             auto load_word = [&](int64_t dj) -> uint32_t {
-                if (pre && (int64_t)a.n_done + 32 * dj < 0) return ~0u;
+                if (pre && (int64_t)n_done + 32 * dj < 0) return ~0u;
                 return gring32[(base32 + (uint32_t)dj) & mask32];
             };
             struct Wide { uint32_t w[JW]; };
@@ -170,7 +151,7 @@ __global__ __launch_bounds__(256) void recc_bits_kernel(FrontArgs a)
             bool hit_prev = false;
 
             auto emit_prev = [&](uint32_t ma) {          // the block before the current one (rare: it held a match)
-                ndet = bits_emit_block<JW, D>(dblk_prev, m_prev[0], m_prev[1], m_prev[2], m_prev[3], mb_prev, ma, E0, E1, a.n_done, dst, ndet, a.det_cap, a.status);
+                ndet = bits_emit_block<JW, D>(dblk_prev, m_prev[0], m_prev[1], m_prev[2], m_prev[3], mb_prev, ma, E0, E1, n_done, dst, ndet, det_cap, status);
             };
 
             // one block: window exchange through LDS, match words of the lane's J dwords, deferred emission of the block before
@@ -201,10 +182,10 @@ __global__ __launch_bounds__(256) void recc_bits_kernel(FrontArgs a)
                 auto sym = [](int i) -> bool { return ((i < 64 ? TRIG_LO >> i : TRIG_HI >> (i - 64)) & 1ull) != 0; };
                 uint32_t m[JW] = {};
                 if constexpr (TOL) {
-                    // tolerant sync (cfg.sync_tolerance): at most a.tol of the 74 symbols differ.  The mismatch words of the
+                    // tolerant sync (cfg.sync_tolerance): at most tol of the 74 symbols differ.  The mismatch words of the
                     // taps are summed bit-sliced: carry-save adders (Harley-Seal) keep the weights 1, 2, 4 in three words
                     // and emit one weight-8 word per eight taps, which ripples into the planes 8..64; the 7-bit sums are
-                    // then compared with a.tol plane by plane.  ~2 instructions per tap instead of ~16 for a ripple counter.
+                    // then compared with tol plane by plane.  ~2 instructions per tap instead of ~16 for a ripple counter.
                     auto csa = [](uint32_t &h, uint32_t &l, uint32_t x, uint32_t y, uint32_t z) {
                         const uint32_t u = x ^ y;
                         h = (x & y) | (u & z);
@@ -243,7 +224,7 @@ __global__ __launch_bounds__(256) void recc_bits_kernel(FrontArgs a)
                         uint32_t gt = 0u, eq = ~0u;
 #pragma unroll
                         for (int pl = 6; pl >= 0; pl--) {
-                            const uint32_t kb = 0u - ((a.tol >> pl) & 1u);
+                            const uint32_t kb = 0u - ((tol >> pl) & 1u);
                             gt |= eq & plane[pl] & ~kb;
                             eq &= ~(plane[pl] ^ kb);
                         }
@@ -295,6 +276,38 @@ __global__ __launch_bounds__(256) void recc_bits_kernel(FrontArgs a)
             }
             if (hit_prev) emit_prev(0u);
         }
+    }
+    return ndet;
+}
+
+template <int SPS, bool TOL = false>
+__global__ __launch_bounds__(256) void recc_bits_kernel(FrontArgs a)
+{
+#ifdef BITS_TIMELINE
+    const unsigned long long tl_t0 = __builtin_amdgcn_s_memtime();
+#endif
+    // window of one wave: [KP - h] = the h-th dword before the block (h = 1..K), [KP + q] = dword q of the block
+    __shared__ __attribute__((aligned(16))) uint32_t s_w_all[4][8 + 64 * 4];
+    front_housekeeping(a);
+
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    uint32_t *s_w = s_w_all[wv];
+    const uint32_t w_id = blockIdx.x * 4 + wv;
+    const uint64_t Tc = a.tiles_per_channel;
+    const uint64_t g_end_all = (uint64_t)a.n_channels * Tc;
+    uint64_t g0 = (uint64_t)w_id * a.span;
+    uint64_t g1 = g0 + a.span; if (g1 > g_end_all) g1 = g_end_all;
+
+    while (g0 < g1) {                                    // one segment = a run of tiles inside one channel
+        const int c = (int)(g0 / Tc);
+        const uint32_t t_lo = (uint32_t)(g0 - (uint64_t)c * Tc);
+        uint32_t t_hi = t_lo + (uint32_t)(g1 - g0); if (t_hi > Tc) t_hi = (uint32_t)Tc;
+        const uint32_t chunk = w_id - (uint32_t)(((uint64_t)c * Tc) / a.span);   // k-th segment of this channel
+        g0 += (uint64_t)(t_hi - t_lo);
+        uint64_t *dst = a.det + ((uint64_t)c * a.max_chunks + chunk) * a.det_cap;
+        const uint32_t ndet = bits_search_segment<SPS, TOL>(a.gring + (uint64_t)c * a.ring_words, a.ring_words, a.n_done, a.P, a.tol, a.status, t_lo, t_hi, s_w, dst,
+                                                            a.det_cap, lane);
         if (lane == 0) a.detcount[(uint64_t)c * a.max_chunks + chunk] = ndet < a.det_cap ? ndet : a.det_cap;
     }
 #ifdef BITS_TIMELINE

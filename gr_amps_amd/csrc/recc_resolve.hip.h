@@ -13,6 +13,7 @@
 // ~25 us per push for the same work.  That form is kept for handles with few channels: resolve_uses_queue.)  Latency-bound bookkeeping on kilobytes; the HBM-bound work is in recc_front.hip.h.
 #pragma once
 #include "recc_decode.hip.h"
+#include "recc_bits.hip.h"
 
 namespace amps {
 
@@ -45,6 +46,12 @@ struct ResolveArgs {
     uint64_t *capq;            // [capq_cap] (channel << CAPQ_POS_BITS | n_c), or null: decode in this kernel
     uint32_t *capq_count;      // atomic; cleared by the streaming kernel's housekeeping
     uint32_t capq_cap;
+    // search stage (recc_resolve_kernel<..., SEARCH = samples per symbol>, the wideband seam since round 6): the bit-domain trigger search of
+    // recc_bits_kernel runs INSIDE this kernel, a quarter of the channel's push per wave, its hits go to LDS lists instead of det /
+    // detcount -- one launch and one kernel boundary fewer per step
+    uint32_t search_P;         // samples of this push (multiple of 64); the stream position of its first sample is n_proc - search_P
+    uint32_t search_tol;       // accepted mismatching trigger symbols (cfg.sync_tolerance)
+    uint32_t *zero1, *zero2;   // the launch's housekeeping (front_housekeeping): the capture queue count / the idle record list's words
     unsigned long long *tl;    // -DRESOLVE_TIMELINE builds: [C][24] s_memtime stamps of every workgroup's thread 0 (scripts/resolve_timeline.py)
 };
 #ifdef RESOLVE_TIMELINE
@@ -176,9 +183,18 @@ constexpr int RESOLVE_LDS_HITS_WIDE = 2048;
 // A batch of THREADS segments with more hits than the LDS window holds is walked in several passes (the hold-off state
 // carries from pass to pass exactly as it does from batch to batch), so no hit count overflows this kernel.
 // TWO = two samples per symbol (a.sps == 2): the capture rule of the wideband seam at D = 768 (manchester_from_ring)
-template <int THREADS, int HITS, bool TWO = false>
+// SEARCH = 0: the trigger hits come from det / detcount (written by the streaming kernel or by recc_bits_kernel); SEARCH = 2 or 3 (samples
+// per symbol): the workgroup searches its channel's slicer bits itself first (bits_search_segment, one quarter of the push per wave).
+// The stand-alone search kernel took 13.5 us per wideband step at D = 768, 7 of them instruction issue and the rest what ANY launch costs;
+// in here its issue slots are the ones this latency-bound kernel leaves idle, and a kernel boundary (~5 us) goes with it.
+constexpr int RESOLVE_SEARCH_CAP = 320;    // hits per quarter: a quarter of the largest push (2^18 / 4 frames) holds at most 65 536 / (74 sps) of them
+template <int THREADS, int HITS, bool TWO = false, int SEARCH = 0, bool STOL = false>
 __global__ __launch_bounds__(THREADS, 4) void recc_resolve_kernel(ResolveArgs a)
 {
+    static_assert(SEARCH == 0 || (THREADS == 256 && (SEARCH == 2 || SEARCH == 3)), "the search stage runs in the narrow kernel, at the wideband seam's rates");
+    __shared__ __attribute__((aligned(16))) uint32_t s_sw[SEARCH ? 4 : 1][SEARCH ? 8 + 64 * 4 : 1];   // the search's LDS window per wave
+    __shared__ uint64_t s_sdet[SEARCH ? 4 : 1][SEARCH ? RESOLVE_SEARCH_CAP : 1];
+    __shared__ uint32_t s_scnt[4];
     __shared__ uint64_t s_hits[HITS];
     __shared__ uint32_t s_scan[THREADS / 64];                      // wave totals of the count scan
     __shared__ uint64_t s_acc[HITS + 1];                           // +1: the pending capture of an earlier push
@@ -193,13 +209,29 @@ __global__ __launch_bounds__(THREADS, 4) void recc_resolve_kernel(ResolveArgs a)
     const uint64_t span_done = (uint64_t)a.sps * (AMPS_RECC_CAPTURE_SYMS + 1) + (a.track ? AMPS_TRACK_BLOCKS : 0);   // + the most the sampling instants can move
     // (the first batch's hit counts are fetched HERE, beside the channel's state: they used to be the third dependent global load of a
     // workgroup's first 3 us)
+    uint64_t next_allowed = a.next_allowed[c];                        // uniform across the block
+    uint64_t pend = a.pending[c];
+    if constexpr (SEARCH != 0) {
+        if (blockIdx.x == 0 && tid == 0) {                            // the launch's housekeeping (front_housekeeping)
+            if (a.zero1) *a.zero1 = 0u;
+            if (a.zero2) { a.zero2[0] = 0u; a.zero2[1] = 0u; a.zero2[2] = 0u; }
+        }
+        // wave w searches tiles [Tc w / 4, Tc (w + 1) / 4) of the push: the run starts of [512 t_lo - 64, min(512 t_hi, P) - 64), in order
+        const uint32_t Tc = (a.search_P + TILE - 1) / TILE;
+        const uint32_t t_lo = (uint32_t)((uint64_t)Tc * (uint32_t)wv / 4u), t_hi = (uint32_t)((uint64_t)Tc * ((uint32_t)wv + 1u) / 4u);
+        uint32_t nd = 0;
+        if (t_hi > t_lo)
+            nd = bits_search_segment<SEARCH, STOL>(a.gring + (uint64_t)c * a.ring_words, a.ring_words, a.n_proc - a.search_P, a.search_P, a.search_tol, a.status,
+                                                   t_lo, t_hi, s_sw[wv], s_sdet[wv], (uint32_t)RESOLVE_SEARCH_CAP, lane);
+        if (lane == 0) s_scnt[wv] = nd < (uint32_t)RESOLVE_SEARCH_CAP ? nd : (uint32_t)RESOLVE_SEARCH_CAP;
+        __syncthreads();
+    }
     const uint32_t n_first = [&]() -> uint32_t {
+        if constexpr (SEARCH != 0) return (uint32_t)tid < 4u ? s_scnt[tid] : 0u;
         const uint64_t gs0 = (uint64_t)c * a.tiles_per_channel;
         const uint32_t nch = (uint32_t)((gs0 + a.tiles_per_channel - 1) / a.span - gs0 / a.span) + 1;
         return (uint32_t)tid < nch ? a.detcount[(uint64_t)c * a.max_chunks + (uint32_t)tid] : 0u;
     }();
-    uint64_t next_allowed = a.next_allowed[c];                        // uniform across the block
-    uint64_t pend = a.pending[c];
     auto centre = [](uint64_t ei) -> uint64_t { return (ei >> 8) + (uint32_t)(ei & 0xff) / 2; };   // of the run of matching phases
 
     // accepted captures are collected in LDS; the first CAP_WAVES waves then capture and decode them, one each per round.  The
@@ -258,9 +290,10 @@ __global__ __launch_bounds__(THREADS, 4) void recc_resolve_kernel(ResolveArgs a)
 
     // segments of channel c: waves floor(c*Tc/span) .. floor((c*Tc + Tc - 1)/span), in stream order
     const uint64_t gs = (uint64_t)c * a.tiles_per_channel;
-    const uint32_t nchunks = (uint32_t)((gs + a.tiles_per_channel - 1) / a.span - gs / a.span) + 1;
-    const uint32_t *cnt = a.detcount + (uint64_t)c * a.max_chunks;
-    const uint64_t *det = a.det + (uint64_t)c * a.max_chunks * a.det_cap;
+    const uint32_t nchunks = SEARCH != 0 ? 4u : (uint32_t)((gs + a.tiles_per_channel - 1) / a.span - gs / a.span) + 1;
+    const uint32_t *cnt = SEARCH != 0 ? s_scnt : a.detcount + (uint64_t)c * a.max_chunks;
+    const uint64_t *det = SEARCH != 0 ? &s_sdet[0][0] : a.det + (uint64_t)c * a.max_chunks * a.det_cap;
+    const uint32_t det_cap = SEARCH != 0 ? (uint32_t)RESOLVE_SEARCH_CAP : a.det_cap;
 
     for (uint32_t cb = 0; cb < nchunks; cb += THREADS) {
         // ---- compaction of up to THREADS segments into LDS, order preserved
@@ -282,7 +315,7 @@ __global__ __launch_bounds__(THREADS, 4) void recc_resolve_kernel(ResolveArgs a)
         __syncthreads();
         const uint32_t batch_total = s_total;
         RTL(1);
-        const uint64_t *d = det + (uint64_t)ch * a.det_cap;
+        const uint64_t *d = det + (uint64_t)ch * det_cap;
         for (uint32_t win = 0; win == 0 || win < batch_total; win += HITS) {
             if (tid == 0) { s_pend = ~0ull; s_na_out = next_allowed; }
             for (uint32_t i = 0; i < n; i++) {

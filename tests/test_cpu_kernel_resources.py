@@ -59,11 +59,14 @@ def test_streaming_kernel_budget(res):
 def test_small_kernels_fit_many_per_cu(res):
     for name, r in list(_one(res, "void amps::recc_bits_kernel<3, false>").items()) + list(_one(res, "void amps::recc_bits_kernel<2, false>").items()):
         assert r["vgprs"] <= 168 and r["lds_bytes"] <= 8192 and r["scratch_bytes_per_lane"] == 0, (name, r)   # issue-bound: 3 waves per SIMD are enough
-    assert len(_one(res, "void amps::recc_resolve_kernel<256, 512, ")) == 2          # the default capture rule, and the one for two samples per symbol
-    for name, r in _one(res, "void amps::recc_resolve_kernel<256, 512, ").items():
-        # resolve + capture + decode, one workgroup per channel: four of them per CU (832 channels on 256 CUs in one round);
-        # static LDS + at most 28 KB of dynamic decode scratch (sps 10) stays under 40 KB
-        assert r["vgprs"] <= 128 and r["waves_per_simd"] >= 4 and r["lds_bytes"] <= 12 * 1024, (name, r)
+    # six narrow instantiations: the two capture rules reading hit lists from HBM (the IQ seam, AMPS_RECC_BITS_KERNEL=separate) and, for the
+    # wideband seam, with the trigger search inside (round 6: 2 / 3 samples per symbol, exact / tolerant): 23.8 KB of static LDS + 14.5 KB of
+    # decode scratch per workgroup -- four of them per CU still (832 channels on 256 CUs in one round)
+    hits = _one(res, "void amps::recc_resolve_kernel<256, 512, ")
+    assert len(hits) == 6, sorted(hits)
+    for name, r in hits.items():
+        assert r["vgprs"] <= 128 and r["waves_per_simd"] >= 4 and r["scratch_bytes_per_lane"] == 0, (name, r)
+        assert r["lds_bytes"] <= (12 if ", 0, false>" in name else 24) * 1024, (name, r)
 
 
 def test_no_kernel_spills_into_the_hot_path_unnoticed(res):
