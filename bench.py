@@ -495,7 +495,9 @@ def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, w
     tm_all = r.timing()
     n_all = max(warmup, 1)
     # in the timed region only the dominant kernel is bracketed: ten event records per step cost ~3 % of the step
-    r.set_timing("dominant")
+    # ... and two event records per step still cost a wideband step 6.5 us = 1.9 % (profiles/r06/event_cost.txt): a long region brackets
+    # the dominant kernel of every eighth push (>= 100 launches timed), a short one (the driver's --steps 20) every push
+    r.set_timing(os.environ.get("AMPS_BENCH_TIMING", "sampled" if steps >= 800 else "dominant"))
     checked = None
     if recs is not None:   # sanity: the decode path really ran -- the planted bursts came back with the transmitted MIN
         if wide:           # a burst cut by the edge of the repeated block may be lost; nearly all must decode

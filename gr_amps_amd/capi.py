@@ -393,7 +393,8 @@ class Recc:
 
     def push_wideband_dist(self, iq, nsamp=None, root=0, mode="broadcast"):
         """every rank in step; the root passes its block (a CUDA tensor, used in place, or a numpy array, staged), the others None.
-        mode: "broadcast" (flat ncclBroadcast) or "scatter_allgather".  Returns the number of samples pushed: the ROOT's, on every rank."""
+        mode: "broadcast" (flat ncclBroadcast) or "scatter_allgather".  Returns the number of samples pushed: the ROOT's, on every rank.
+        The root passing None ends the stream: every rank's call raises AmpsError with code -errno.ENODATA, nothing is pushed."""
         ptr, mem, n = None, MEM_DEVICE, 0
         if iq is not None:
             if isinstance(iq, np.ndarray):
@@ -587,8 +588,9 @@ class Recc:
         return d[:p], s[:p], g[:p]
 
     def set_timing(self, mode):
-        """mode: "off" | "all" | "dominant" (only the streaming kernel of the seam in use is bracketed by HIP events)"""
-        rc = load().amps_recc_set_timing(self._h, {"off": 0, "all": 1, "dominant": 2}[mode])
+        """mode: "off" | "all" | "dominant" (only the streaming kernel of the seam in use is bracketed by HIP events) |
+        "sampled" (the dominant kernel of every eighth push)"""
+        rc = load().amps_recc_set_timing(self._h, {"off": 0, "all": 1, "dominant": 2, "sampled": 3}[mode])
         if rc:
             raise AmpsError(rc, "amps_recc_set_timing")
 

@@ -114,6 +114,7 @@ struct amps_recc {
     // ---- timing ----
     bool timing = false;
     int timing_mode = 0;              // AMPS_RECC_TIMING_*
+    uint32_t dominant_tick = 0;       // launches of the dominant kernel seen in DOMINANT_SAMPLED mode
     std::vector<hipEvent_t> event_pool;   // recycled by collect_spans
     std::vector<TimedSpan> spans;
     double ms[T_COUNT] = { 0 };
@@ -182,7 +183,8 @@ struct SpanGuard {   // records a pair of events around a launch when timing is 
     {
         // "dominant" mode: only the streaming kernel of the seam (front kernel, or the channelizer on the wideband
         // seam) is bracketed -- two event records per push instead of ten, for timed regions that should not be perturbed
-        if (on && h->timing_mode == AMPS_RECC_TIMING_DOMINANT) on = (tag == T_CHANNELIZER) || (tag == T_FRONT && !h->chz.enabled);
+        if (on && h->timing_mode >= AMPS_RECC_TIMING_DOMINANT) on = (tag == T_CHANNELIZER) || (tag == T_FRONT && !h->chz.enabled);
+        if (on && h->timing_mode == AMPS_RECC_TIMING_DOMINANT_SAMPLED) on = (h->dominant_tick++ % AMPS_RECC_TIMING_SAMPLE_PERIOD) == 0;
         if (!on) return;
         a = take(h); b = take(h);
         if (!a || !b) { on = false; return; }
@@ -563,6 +565,7 @@ const char *amps_recc_strerror(int code)
     case ENOTCONN: return "the handle's communicator has been aborted";
     case ESTALE: return "the communicator died with collectives in flight: stream state and record lists are void until amps_recc_reset";
     case EREMOTEIO: return "another rank reported an error: no rank ran the collective";
+    case ENODATA: return "end of stream: the root of the distributed push has no more samples";
     default: return "unknown error";
     }
 }
@@ -1055,7 +1058,8 @@ int amps_recc_push_wideband_dist(amps_recc_t *h, const float *iq, size_t nsamp, 
     const float2 *blk = nullptr;
     int slot = 0;
     size_t n = 0;
-    // (a missing block or nsamp = 0 at the root is the root's error and travels through the header: the other ranks learn of it)
+    // (a missing block or nsamp = 0 at the root is the root's error -- both together its END OF STREAM, -ENODATA on every rank -- and
+    // travels through the header: the other ranks learn of it)
     if (int rc = rccl_distribute(h->rccl, (const float2 *)iq, mem == AMPS_MEM_HOST, nsamp, root, mode, h->stream, &blk, &slot, &n)) return rc;
     const int rc = amps_recc_push_wideband(h, (const float *)blk, n, AMPS_MEM_DEVICE);
     const int rc2 = rccl_block_consumed(h->rccl, slot, h->stream);
@@ -1424,11 +1428,12 @@ int amps_recc_set_origin(amps_recc_t *h, uint64_t first_sample)
 
 int amps_recc_set_timing(amps_recc_t *h, int mode)
 {
-    if (!h || mode < AMPS_RECC_TIMING_OFF || mode > AMPS_RECC_TIMING_DOMINANT) return -EINVAL;
+    if (!h || mode < AMPS_RECC_TIMING_OFF || mode > AMPS_RECC_TIMING_DOMINANT_SAMPLED) return -EINVAL;
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     collect_spans(h);
     h->timing_mode = mode;
+    h->dominant_tick = 0;
     h->timing = mode != AMPS_RECC_TIMING_OFF;
     h->rccl.timing = h->timing;
     return 0;

@@ -341,11 +341,21 @@ inline int rccl_distribute(RcclState &r, const float2 *root_block, bool root_blo
     uint32_t own = 0;
     if (mode != RCCL_DIST_BROADCAST && mode != RCCL_DIST_SCATTER_ALLGATHER) own = EINVAL;
     if (r.rank == root) {
-        if (!root_block || nsamp_arg == 0) own = EINVAL;
+        // END OF STREAM: the root pushing (NULL, 0) says it has no more samples.  That is not an error: it travels in the
+        // header's status word as ENODATA, EVERY rank returns -ENODATA from this call, no data collective follows and the communicator
+        // stays up (a later push with samples continues the stream) -- so ranks whose own sources end at other times than the root's can
+        // keep joining until they see it instead of running into their bound.
+        if (!root_block && nsamp_arg == 0) own = ENODATA;
+        else if (!root_block || nsamp_arg == 0) own = EINVAL;
         else if (nsamp_arg > r.cap_common) own = E2BIG;
     }
     const uint32_t mine[RCCL_HDR_WORDS] = { own, (uint32_t)mode, (uint32_t)(nsamp_arg & 0xffffffffu), (uint32_t)((uint64_t)nsamp_arg >> 32) };
     if (int e = rccl_exchange(r, mine)) return e;
+    if (rccl_hdr_of(r, root)[0] == (uint32_t)ENODATA && own == (r.rank == root ? (uint32_t)ENODATA : 0u)) {
+        bool others_fine = true;
+        for (int k = 0; k < r.nranks; k++) if (k != root && rccl_hdr_of(r, k)[0]) others_fine = false;
+        if (others_fine) return -ENODATA;
+    }
     if (int v = rccl_verdict(r, own)) return v;
     for (size_t k = 0; k < N; k++) if (rccl_hdr_of(r, (int)k)[1] != (uint32_t)mode) return -EINVAL;   // the ranks disagree: everybody sees it
     const size_t nsamp = (size_t)(((uint64_t)rccl_hdr_of(r, root)[3] << 32) | rccl_hdr_of(r, root)[2]);

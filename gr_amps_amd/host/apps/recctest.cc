@@ -159,6 +159,7 @@ int main(int argc, char **argv)
                 gr_vector_const_void_star ins = { data.data() + 8 * off };
                 if (src->work(n, ins, outs) != 0) return 1;
             }
+            src->stop();                                              // as the scheduler does: the root announces its end of stream, the others join until they see it
         } else if (mode == "syms") {
             auto src = gr::amps::recc::make();
             gr::msg_connect(src, "bursts", dec, "bursts");

@@ -133,6 +133,8 @@ public:
     block(const std::string &name, io_signature::sptr in, io_signature::sptr out) : basic_block(name, in, out) {}
     block() {}
     virtual void forecast(int, gr_vector_int &) {}
+    virtual bool start() { return true; }      // gr::block::start / stop: called by the scheduler when the flow graph starts / has stopped
+    virtual bool stop() { return true; }
     virtual int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
                              gr_vector_void_star &output_items) = 0;
     void consume_each(int n) { d_consumed += n; }

@@ -19,6 +19,7 @@ class recc_wideband_impl : public recc_wideband {
     bool d_bcast = false;                          // set_rccl: the stream comes from rank d_root by RCCL
     int d_root = 0, d_rank = 0, d_mode = AMPS_RECC_DIST_BROADCAST;
     unsigned long long d_stream_samples = 0, d_paced_items = 0;   // non-root ranks: samples the root has distributed / items this rank's pacing input has offered
+    bool d_ended = false;                          // the root's end of stream has been sent (root) / seen (the others)
 
 public:
     recc_wideband_impl(int C, int first_bin, int slicer, int groups, int group, int decim)
@@ -69,6 +70,7 @@ public:
             rc = amps_recc_push_wideband_dist(d_handle, root ? in : nullptr, root ? n : 0, AMPS_MEM_HOST, d_root, d_mode, &pushed);
             d_stream_samples += pushed;
         } else rc = amps_recc_push_wideband(d_handle, in, n, AMPS_MEM_HOST);
+        if (rc == -ENODATA) { d_ended = true; return false; }   // the root's stream has ended: a clean WORK_DONE, the communicator is left alone
         if (rc != 0) { std::fprintf(stderr, "amps::recc_wideband: %s\n", amps_recc_strerror(rc)); return leave(); }
         size_t nrec = 0;
         rc = amps_recc_drain_bursts(d_handle, d_recs.data(), d_bursts.data(), kMaxRecs, &nrec);
@@ -80,6 +82,18 @@ public:
             const pmt::pmt_t ch = pmt::from_long((long)d_recs[i].channel);
             message_port_pub(pmt::mp("bursts"), pmt::cons(ch, pmt::mp(d_bursts.data() + i * AMPS_RECC_CAPTURE_SYMS, AMPS_RECC_CAPTURE_SYMS)));
             message_port_pub(pmt::mp("records"), pmt::cons(ch, pmt::mp(&d_recs[i], sizeof(d_recs[i]))));
+        }
+        return true;
+    }
+    // The flow graph has stopped (the ranks' sources end at different times).  The root tells the others -- one header
+    // exchange, -ENODATA on every rank, no data collective; the others keep joining the root's collectives (and publishing their records)
+    // until they see it, so the root's last blocks are not lost on ranks whose pacing source ended first.  A root that died instead
+    // is what the bounded waits are for.
+    bool stop() override
+    {
+        if (d_bcast && !d_ended) {
+            if (d_rank == d_root) { (void)amps_recc_push_wideband_dist(d_handle, nullptr, 0, AMPS_MEM_HOST, d_root, d_mode, nullptr); d_ended = true; }
+            else while (!d_ended && push_and_publish(nullptr, 0)) { }
         }
         return true;
     }

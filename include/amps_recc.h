@@ -353,8 +353,12 @@ int amps_recc_rccl_abort(amps_recc_t *h);
  * block is read in place, behind everything enqueued on the handle's stream so far (so amps_recc_wait_event orders it behind its
  * producer), and may be overwritten by work that is ordered behind a LATER call on this handle (amps_recc_record_event) or after a
  * drain that covers this push.  Records are drained per rank as ever (or by amps_recc_drain_gather) and carry whole-band channel numbers.
- * Errors: the root's -EINVAL (no block, nsamp = 0, unknown mode) / -E2BIG (beyond the smallest rank's capacity) with -EREMOTEIO on the
- * other ranks; -EINVAL everywhere when the ranks pass different modes; -ETIMEDOUT / -ENOTCONN / -EIO: see above. */
+ * END OF STREAM: the root passing (iq = NULL, nsamp = 0) says it has no more samples -- every rank returns -ENODATA from that call, no
+ * data collective runs, nothing is pushed, the communicator stays up (a later call with samples continues the stream).  Ranks whose
+ * own sources end at other times than the root's keep calling until they see it.
+ * Errors: the root's -EINVAL (a block without samples or samples without a block, unknown mode) / -E2BIG (beyond the smallest rank's
+ * capacity) with -EREMOTEIO on the other ranks; -EINVAL everywhere when the ranks pass different modes; -ETIMEDOUT / -ENOTCONN / -EIO:
+ * see above. */
 int amps_recc_push_wideband_dist(amps_recc_t *h, const float *iq, size_t nsamp, int mem, int root, int mode, size_t *npushed);
 /* = amps_recc_push_wideband_dist(h, iq, nsamp, mem, root, AMPS_RECC_DIST_BROADCAST, NULL) */
 int amps_recc_push_wideband_bcast(amps_recc_t *h, const float *iq, size_t nsamp, int mem, int root);
@@ -406,10 +410,14 @@ int amps_recc_debug_channelize(amps_recc_t *h, const float *iq, size_t nsamp, in
 int amps_recc_get_timing(amps_recc_t *h, amps_recc_timing_t *t, int reset);
 /* HIP-event timing of the launches: OFF, ALL kernels (what AMPS_RECC_FLAG_TIME_KERNELS selects at creation), or only the
  * DOMINANT streaming kernel of the seam in use (front kernel; channelizer on the wideband seam) -- two event records
- * per push instead of ten, for timed regions that should not be perturbed.  Synchronises the stream. */
+ * per push instead of ten, for timed regions that should not be perturbed -- or the dominant kernel of every
+ * AMPS_RECC_TIMING_SAMPLE_PERIOD-th push only (DOMINANT_SAMPLED: the two event records cost a wideband step 6.5 us = 1.9 %,
+ * profiles/r06/event_cost.txt).  Synchronises the stream. */
 #define AMPS_RECC_TIMING_OFF      0
 #define AMPS_RECC_TIMING_ALL      1
 #define AMPS_RECC_TIMING_DOMINANT 2
+#define AMPS_RECC_TIMING_DOMINANT_SAMPLED 3
+#define AMPS_RECC_TIMING_SAMPLE_PERIOD 8
 int amps_recc_set_timing(amps_recc_t *h, int mode);
 
 /* reply generation of recc_decode: fills the focc_words / fvc_words payloads the

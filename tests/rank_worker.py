@@ -96,8 +96,10 @@ def main():
         elif a.scenario == "root_error":
             blk = np.ascontiguousarray(x[:1000000]) if x is not None else None
             out["events"].append(["good", r.push_wideband_dist(blk, None, a.root, a.mode)])
-            rc, _ = code_of(r.push_wideband_dist, None, None, a.root, a.mode)        # the root has no block: its error, everybody's verdict
-            out["events"].append(["root_without_block", rc])
+            rc, _ = code_of(r.push_wideband_dist, blk, 0, a.root, a.mode)            # the root offers a block of no samples: its error, everybody's verdict
+            out["events"].append(["root_without_samples", rc])
+            rc, _ = code_of(r.push_wideband_dist, None, None, a.root, a.mode)        # the root has nothing more: END OF STREAM, the same answer on every rank,
+            out["events"].append(["end_of_stream", rc])                               # no data collective, and the communicator carries on
             out["events"].append(["good_again", r.push_wideband_dist(blk, None, a.root, a.mode)])
             mode = a.mode if a.rank != a.nranks - 1 else ("scatter_allgather" if a.mode == "broadcast" else "broadcast")
             rc, _ = code_of(r.push_wideband_dist, blk, None, a.root, mode)            # the ranks disagree on the mode

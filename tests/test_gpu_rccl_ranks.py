@@ -111,7 +111,8 @@ def test_a_local_error_is_everybodys_verdict_and_the_communicator_survives(strea
     for r, o in enumerate(res):
         ev = dict((e[0], e[1]) for e in o["events"])
         assert ev["good"] == ev["good_again"] == ev["good_after_mismatch"] == 1000000
-        assert ev["root_without_block"] == (-errno.EINVAL if r == 0 else -errno.EREMOTEIO)
+        assert ev["root_without_samples"] == (-errno.EINVAL if r == 0 else -errno.EREMOTEIO)
+        assert ev["end_of_stream"] == -errno.ENODATA            # the root's (NULL, 0): every rank learns the stream has ended, nobody times out
         assert ev["mode_mismatch"] == -errno.EINVAL             # every rank sees all the headers: the same verdict everywhere
 
 
