@@ -17,8 +17,9 @@
  *                                   (grc/recctest.grc:458,846-874,807,310,349 and connections :3238-3274)
  *   amps_recc_push_wideband     <-  N x (freq_xlating_fir_filter_ccc -> the chain above), one per 30 kHz
  *                                   channel (grc/recctest.grc:889-937, taps :115-155); polyphase channelizer
- *                                   front end: M = 1024 branches at fs = 30.72 Msps, D = 512 (60 ksps per
- *                                   channel, samples_per_symbol = 3), 8 taps per branch: the one geometry
+ *                                   front end: M = 1024 branches at fs = 30.72 Msps, 8 taps per branch,
+ *                                   D = 768 (40 ksps per channel, samples_per_symbol = 2; the default) or
+ *                                   D = 512 (60 ksps, samples_per_symbol = 3): the two geometries
  *                                   amps_recc_create accepts (anything else: -EINVAL)
  *   amps_recc_reply_words       <-  handle_response / handle_registration / handle_origination
  *                                   lib/recc_decode_impl.cc:181-272 + word builders lib/amps_packet.cc:26-95
