@@ -91,7 +91,8 @@ def main():
                 cols[name] = np.array([_score(by.get(c, []), *truth[c]) for c in range(NB)]).sum(0)
             print("iq   %3d %5d %6d %5d | %s | %s | %s" % (snr, ppm, cfo, NB, fmt(cols["tracked"], NB), fmt(cols["fixed"], NB), fmt(cols["ref"], NB)), flush=True)
     # ---------------- wideband seam
-    first, Cw, D = 96, 832, 512
+    first, Cw, D = 96, 832, int(os.environ.get("IMP_DECIM", "768"))      # the filter bank's decimation (768 = library default since round 6)
+    print("wideband seam at D = %d" % D, flush=True)
     n = int(0.45 * FS) // D * D
     nout = n * 5 // 384
     assert n % 384 == 0
@@ -122,8 +123,8 @@ def main():
                     planted[c] = (min10, [list(w) for w in words], off, k, blen)
                 sent_total += len(planted)
                 for name, fixed in (("tracked", False), ("fixed", True)):
-                    with capi.Recc(n_channels=Cw, sps=3, max_samples=n // D + 72, max_bursts=4096, fixed_timing=fixed,
-                                   wideband={"channels": 1024, "decim": 512, "taps_per_branch": 8, "first_channel": first}) as r:
+                    with capi.Recc(n_channels=Cw, sps=1536 // D, max_samples=n // D + 72, max_bursts=4096, fixed_timing=fixed,
+                                   wideband={"channels": 1024, "decim": D, "taps_per_branch": 8, "first_channel": first}) as r:
                         r.push_wideband(x)
                         r.push_wideband(torch.zeros(64 * D, dtype=torch.complex64, device=dev))
                         recs = r.drain()
