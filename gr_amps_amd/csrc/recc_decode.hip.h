@@ -349,16 +349,11 @@ __device__ __forceinline__ void manchester_from_ring(DecodeCore &s, const uint64
     // TWO: w starts one sample in front of the pair at the delay the block before was taken at; returns the block's own move
     auto choose2 = [&](uint32_t w, bool on) -> int {
         const uint32_t e = w ^ (w >> 2);                               // bit i clear: samples i and i + 2 are equal
-#ifdef AMPS_WALK_DPP_SUM
+        // (three ballots + scalar population counts instead of the one DPP wave sum: measured slower, 0.0355-0.0367 against 0.0349-0.0353 ms
+        // per wideband step at D = 768 -- a VALU compare feeding the scalar unit waits longer than six v_add_dpp: profiles/EXPERIMENTS.md, round 6)
         const uint32_t contrib = on ? ((~e & 1u) | ((~e & 2u) << 7) | ((~e & 4u) << 14)) : 0u;   // violations at d - 1 | d << 8 | d + 1 << 16
         const uint32_t tot = wave_sum_u32(contrib);
         const uint32_t vm = tot & 0xffu, v0 = (tot >> 8) & 0xffu, vp = tot >> 16;
-#else
-        // three one-bit planes: a ballot and a scalar population count each -- no cross-lane adds on the chain (the DPP wave sum of
-        // rounds 4-6 was six dependent v_add_dpp with their wait states and a v_readlane: profiles/r06/walk_ballot_ab.txt)
-        const uint32_t vm = (uint32_t)__popcll(__ballot(on && !(e & 1u))), v0 = (uint32_t)__popcll(__ballot(on && !(e & 2u))),
-                       vp = (uint32_t)__popcll(__ballot(on && !(e & 4u)));
-#endif
         int mv = 0;
         uint32_t best = v0;
         if (vm < v0) { mv = -1; best = vm; }

@@ -37,11 +37,12 @@ for nb in (() if "wide" in sys.argv[1:] else (0, 1, 2)):
         torch.cuda.synchronize()
         run(r, lambda: r.push_iq(d), "iq832 bursts/channel=%d" % nb)
 # wideband seam, 2^27 samples
-NW = 1 << 27
+DEC = int(os.environ.get("CHZ_DECIM", "512"))            # the filter bank's decimation: 512 (3 samples per symbol) or 768 (2)
+NW = (1 << 27) if DEC == 512 else 11 * 256 * 64 * 768
 for every in (0, 2, 1):
     x, planted = bench.make_wideband_batch(torch, dev, NW, 96, 832 if every else 0, every or 1, seed=3)
-    with capi.Recc(n_channels=832, sps=3, max_samples=NW // 512 + 8, max_bursts=8192, time_kernels=True, sync_torch=False,
-                   wideband={"channels": 1024, "decim": 512, "taps_per_branch": 8, "first_channel": 96}) as r:
+    with capi.Recc(n_channels=832, sps=1536 // DEC, max_samples=NW // DEC + 72, max_bursts=8192, time_kernels=True, sync_torch=False,
+                   wideband={"channels": 1024, "decim": DEC, "taps_per_branch": 8, "first_channel": 96}) as r:
         torch.cuda.synchronize()
         run(r, lambda: r.push_wideband(x), "wide832 bursts=%d" % len(planted))
     del x
