@@ -12,8 +12,9 @@
 //                                      library distributes it (mode 0 = ncclBroadcast, 1 = scatter + all-gather); the other ranks' items only pace
 //                                      them (they may use any chunk).  The 128-byte communicator id travels through <idfile> (rank 0 writes it).
 //                                      Each rank prints the bursts of ITS channel group; the union is what `recctest wide` prints
-//   recctest raw  <file.fc32> [chunk] [center_hz]   the flow graph's own capture format (grc/recctest.grc:591): 400 ksps fc32,
-//                                      channel at center_hz (default +160 kHz, :889-937) -> channel filter + fused chain on the GPU
+//   recctest raw  <file.fc32> [chunk] [center_hz] [cutoff_hz]   the flow graph's own capture format (grc/recctest.grc:591): 400 ksps fc32,
+//                                      channel at center_hz (default +160 kHz, :889-937) -> channel filter + fused chain on the GPU;
+//                                      cutoff_hz (default 0 = the flow graph's 10 kHz) widens the channel filter for mobiles off their carrier
 // Every message published on recc_decode's output ports is printed as one text line, which is what
 // tests/test_gpu_host_blocks.py compares with the oracle.
 #include <amps/recc.h>
@@ -170,7 +171,8 @@ int main(int argc, char **argv)
             }
         } else {
             const double center = argc > 4 ? std::atof(argv[4]) : 160e3;
-            auto src = mode == "raw" ? gr::amps::recc_fused::make(10, 400e3, center, 2) : gr::amps::recc_fused::make(10);
+            const double cutoff = argc > 5 ? std::atof(argv[5]) : 0.0;
+            auto src = mode == "raw" ? gr::amps::recc_fused::make(10, 400e3, center, 2, cutoff) : gr::amps::recc_fused::make(10);
             if (mode == "iqb") gr::msg_connect(src, "bursts", dec, "bursts"); else gr::msg_connect(src, "records", dec, "records");
             const size_t ns = data.size() / 8;
             for (size_t off = 0; off < ns; off += (size_t)chunk) {

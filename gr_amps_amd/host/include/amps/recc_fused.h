@@ -7,6 +7,9 @@
 // With xlate_rate_hz > 0 it also absorbs the flow graph's channel filter (freq_xlating_fir_filter_ccc with the
 // firdes.low_pass taps, grc/recctest.grc:889-937, :115-155): the input is then the raw capture rate (400 ksps in
 // recctest.grc) with the channel at xlate_center_hz, and xlate_rate_hz / xlate_decim = samples_per_symbol * 20 kHz.
+// xlate_cutoff_hz / xlate_width_hz = 0 keep the flow graph's 10 kHz / 4.5 kHz.  A mobile whose carrier is off by 2 kHz loses half its
+// bursts at 12 dB C/N behind THAT filter (it cuts into a signal it no longer centres) and none behind a 14 kHz one of the same length
+// (profiles/r06/cfo_filter_width.txt): a receiver that expects carrier offsets sets xlate_cutoff_hz = 14e3.
 #pragma once
 #include <amps/api.h>
 
@@ -16,7 +19,8 @@ namespace amps {
 class AMPS_API recc_fused : virtual public gr::sync_block {
 public:
     typedef AMPS_SPTR<recc_fused> sptr;
-    static sptr make(int samples_per_symbol = 10, double xlate_rate_hz = 0.0, double xlate_center_hz = 0.0, int xlate_decim = 2);
+    static sptr make(int samples_per_symbol = 10, double xlate_rate_hz = 0.0, double xlate_center_hz = 0.0, int xlate_decim = 2,
+                     double xlate_cutoff_hz = 0.0, double xlate_width_hz = 0.0);
 };
 
 } // namespace amps

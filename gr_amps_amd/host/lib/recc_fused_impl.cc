@@ -20,7 +20,7 @@ class recc_fused_impl : public recc_fused {
     static const int kMaxRecs = 64;
 
 public:
-    recc_fused_impl(int sps, double xlate_rate, double xlate_center, int xlate_decim)
+    recc_fused_impl(int sps, double xlate_rate, double xlate_center, int xlate_decim, double xlate_cutoff, double xlate_width)
         : gr::sync_block("recc_fused", gr::io_signature::make(1, 1, 2 * sizeof(float)), gr::io_signature::make(0, 0, 0)), d_handle(nullptr),
           d_raw(xlate_rate > 0.0), d_bursts((size_t)kMaxRecs * AMPS_RECC_CAPTURE_SYMS)
     {
@@ -40,6 +40,8 @@ public:
             x.decim = (uint32_t)xlate_decim;
             x.rate_hz = xlate_rate;
             x.center_hz = xlate_center;
+            x.cutoff_hz = xlate_cutoff;                    // 0 = the flow graph's 10 kHz / 4.5 kHz
+            x.width_hz = xlate_width;
             rc = amps_recc_set_xlate(d_handle, &x);
             if (rc != 0) {
                 amps_recc_destroy(d_handle);
@@ -79,9 +81,9 @@ public:
     }
 };
 
-recc_fused::sptr recc_fused::make(int samples_per_symbol, double xlate_rate_hz, double xlate_center_hz, int xlate_decim)
+recc_fused::sptr recc_fused::make(int samples_per_symbol, double xlate_rate_hz, double xlate_center_hz, int xlate_decim, double xlate_cutoff_hz, double xlate_width_hz)
 {
-    return gnuradio::get_initial_sptr(new recc_fused_impl(samples_per_symbol, xlate_rate_hz, xlate_center_hz, xlate_decim));
+    return gnuradio::get_initial_sptr(new recc_fused_impl(samples_per_symbol, xlate_rate_hz, xlate_center_hz, xlate_decim, xlate_cutoff_hz, xlate_width_hz));
 }
 
 } // namespace amps

@@ -124,3 +124,42 @@ def test_xlate_argument_errors(gpu):
         r.set_xlate(rate_hz=400e3, center_hz=160e3, decim=2)
         with pytest.raises(capi.AmpsError):
             r.push_raw(np.zeros((1, 2 * 4096 + 2), np.complex64))        # more than decim * max_samples
+
+
+def test_a_wider_channel_filter_keeps_mobiles_that_are_off_their_carrier(gpu):
+    """VERDICT r05 item 8 (carrier offset on the IQ seam): a mobile 2 kHz off its carrier loses half its bursts at 12 dB C/N behind the
+    flow graph's channel filter -- cut-off 10 kHz, grc/recctest.grc:115-155: it cuts into a signal it no longer centres; the restated
+    reference chain loses four fifths there -- and none behind a 14 kHz filter of the same length on the same seam
+    (amps_recc_xlate_cfg_t.cutoff_hz; 500 bursts per point: profiles/r06/cfo_filter_width.txt).  Without an offset the two filters
+    decode the same bursts."""
+    nb, n400 = 96, 80000
+    snr400 = 12.0 - 10.0 * np.log10(400.0 / 30.0)
+
+    def blocks(cfo):
+        raw, truth = [], []
+        for i in range(nb):
+            x, t = synth.make_channel_block(n400, 1, seed=881000 + i, sps=20, snr_db=snr400, first=4000, cfo_hz=cfo)
+            raw.append((x * np.exp(2j * np.pi * 0.4 * np.arange(x.size))).astype(np.complex64))
+            truth.append((t[0][2], [bytes(np.asarray(w, np.uint8)) for w in t[0][5]]))
+        return np.stack(raw), truth
+
+    def good(raw, truth, cutoff):
+        with capi.Recc(n_channels=nb, sps=10, max_samples=n400 // 2 + 64, max_bursts=4 * nb) as r:
+            r.set_xlate(rate_hz=400e3, center_hz=160e3, decim=2, cutoff_hz=cutoff)
+            r.push_raw(raw)
+            r.push_raw(np.zeros((nb, 2048), np.complex64))
+            recs = r.drain()
+        ok = set()
+        for g in recs:
+            min10, sent = truth[int(g["channel"])]
+            if g["min"].decode() == min10 and all(bool(g["valid"][w]) and bytes(g["word_dec"][w]) == sent[w] for w in range(len(sent))):
+                ok.add(int(g["channel"]))
+        return len(ok)
+
+    raw, truth = blocks(2000.0)
+    narrow, wide = good(raw, truth, 0.0), good(raw, truth, 14e3)
+    print("2 kHz off the carrier at 12 dB: %d of %d bursts behind the 10 kHz filter, %d behind the 14 kHz one" % (narrow, nb, wide))
+    assert wide >= nb - 2 and narrow <= (3 * nb) // 4
+    raw, truth = blocks(0.0)
+    narrow0, wide0 = good(raw, truth, 0.0), good(raw, truth, 14e3)
+    assert narrow0 >= nb - 1 and wide0 >= nb - 1
