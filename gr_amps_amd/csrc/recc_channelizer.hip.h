@@ -987,7 +987,12 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
     // would then run AFTER the fold instead of beside it.  So the latency-bound roles get the oldest waves and a higher priority
     // (measured, ms per GiB, spec C / A: fold in the oldest waves and no priorities 0.440 / 0.592; priorities alone 0.390 /
     // 0.505; order alone 0.395 / 0.502; both 0.387 / 0.503; round 2's two-role kernel on the same box 0.387 / 0.532).
-    const int role = 2 - (wave >> 2);                                   // 0 fold (waves 8..11), 1 pass 2 (4..7), 2 pass 3 + slicer (0..3)
+#ifndef CHZ_ROLE_G0
+#define CHZ_ROLE_G0 2
+#define CHZ_ROLE_G1 1
+#define CHZ_ROLE_G2 0
+#endif
+    const int role = (wave >> 2) == 0 ? CHZ_ROLE_G0 : (wave >> 2) == 1 ? CHZ_ROLE_G1 : CHZ_ROLE_G2;   // 0 fold (waves 8..11), 1 pass 2 (4..7), 2 pass 3 + slicer (0..3)
     // Which role runs pass 3.  Behind the cheap slicers (specs B, C: 7 instructions per channel pair and frame) it shares the
     // slicer's waves; spec A's arctangent makes the slicer the longest chain of a time step (46 instructions per pair and
     // frame), so there pass 3 moves to the pass-2 waves (spec A 0.537 -> 0.517 ms, spec C 0.399 -> 0.414 if it moved too).
@@ -1002,16 +1007,20 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
     const uint32_t p3_v = 64u * (uint32_t)wf + (uint32_t)lane;
     const bool p3_on = p3_v < 4u * a.grp_w;
     const int p3_f = (int)(p3_v / a.grp_w) & 3, p3_i = (int)(a.grp_r * a.grp_w + p3_v % a.grp_w);
+    // Priorities.  Rounds 3-5: pass 3 + slicer 2, pass 2 1, fold 0 (six other triples within the noise at D = 512 under specs A / C).  Round 6,
+    // with the fold the longest chain of a step at either decimation (chz_timeline: 2575 of 3445 cycles at D = 768, the pass-2 role idle for
+    // 1650): the FOLD ABOVE PASS 2 -- pass 3 + slicer 2, fold 1, pass 2 0 -- is 1.8-3.3 % faster under spec D at D = 768, 1.4-5 % under
+    // B / C, 0.8-3.2 % at D = 512 (every triple with pass 2 lowest gains 2-3 %; profiles/r06/prio_ab.txt).  Spec A, whose pass-2 waves also
+    // run pass 3, loses 4-8 % by it and keeps the old order, as does the unfused form.
 #ifndef CHZ_PRIO_SLICER
-#define CHZ_PRIO_SLICER 2
-#define CHZ_PRIO_PASS2 1
-#define CHZ_PRIO_FOLD 0
+    constexpr bool FOLD_OVER_P2 = !IQ && SL != AMPS_SLICER_ATAN_BOXCAR;
+    constexpr int CHZ_PRIO_SLICER = 2, CHZ_PRIO_PASS2 = FOLD_OVER_P2 ? 0 : 1, CHZ_PRIO_FOLD = FOLD_OVER_P2 ? 1 : 0;
 #endif
-    if (role == 2) __builtin_amdgcn_s_setprio(CHZ_PRIO_SLICER); else if (role == 1) __builtin_amdgcn_s_setprio(CHZ_PRIO_PASS2); else __builtin_amdgcn_s_setprio(CHZ_PRIO_FOLD);   // (six other priority triples measured in round 3, four under spec D in round 4: all within the run-to-run noise of this one)
+    if (role == 2) __builtin_amdgcn_s_setprio(CHZ_PRIO_SLICER); else if (role == 1) __builtin_amdgcn_s_setprio(CHZ_PRIO_PASS2); else __builtin_amdgcn_s_setprio(CHZ_PRIO_FOLD);
     // The next launch's carry (the last L - D + 4 D samples and the leftover) is a ~80 KB copy: every workgroup moves its slice
     // here, a sample per thread of wave 0, instead of a kernel of its own behind this one (4.4 us + a launch gap per push).  Not
     // in the fold waves: their vmcnt windows count their own loads only.
-    if (a.carry_out && wave == 0) {
+    if (a.carry_out && role == 2 && wf == 0) {
         const uint32_t per = (a.carry_out_len + gridDim.x - 1) / gridDim.x;
         const uint32_t k0 = blockIdx.x * per;
         const uint32_t k1 = k0 + per < a.carry_out_len ? k0 + per : a.carry_out_len;
