@@ -987,12 +987,9 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
     // would then run AFTER the fold instead of beside it.  So the latency-bound roles get the oldest waves and a higher priority
     // (measured, ms per GiB, spec C / A: fold in the oldest waves and no priorities 0.440 / 0.592; priorities alone 0.390 /
     // 0.505; order alone 0.395 / 0.502; both 0.387 / 0.503; round 2's two-role kernel on the same box 0.387 / 0.532).
-#ifndef CHZ_ROLE_G0
-#define CHZ_ROLE_G0 2
-#define CHZ_ROLE_G1 1
-#define CHZ_ROLE_G2 0
-#endif
-    const int role = (wave >> 2) == 0 ? CHZ_ROLE_G0 : (wave >> 2) == 1 ? CHZ_ROLE_G1 : CHZ_ROLE_G2;   // 0 fold (waves 8..11), 1 pass 2 (4..7), 2 pass 3 + slicer (0..3)
+    const int role = 2 - (wave >> 2);                                   // 0 fold (waves 8..11), 1 pass 2 (4..7), 2 pass 3 + slicer (0..3)
+    // (round 6, under the priorities below: the other wave orders of the three roles -- fold | pass 2 | slicer, fold | slicer | pass 2,
+    // slicer | fold | pass 2, pass 2 | slicer | fold -- are within 1 % of this one: profiles/r06/prio_ab.txt)
     // Which role runs pass 3.  Behind the cheap slicers (specs B, C: 7 instructions per channel pair and frame) it shares the
     // slicer's waves; spec A's arctangent makes the slicer the longest chain of a time step (46 instructions per pair and
     // frame), so there pass 3 moves to the pass-2 waves (spec A 0.537 -> 0.517 ms, spec C 0.399 -> 0.414 if it moved too).
@@ -1020,7 +1017,7 @@ __global__ __launch_bounds__(768, 3) void chz12_kernel(ChzArgs a)
     // The next launch's carry (the last L - D + 4 D samples and the leftover) is a ~80 KB copy: every workgroup moves its slice
     // here, a sample per thread of wave 0, instead of a kernel of its own behind this one (4.4 us + a launch gap per push).  Not
     // in the fold waves: their vmcnt windows count their own loads only.
-    if (a.carry_out && role == 2 && wf == 0) {
+    if (a.carry_out && wave == 0) {
         const uint32_t per = (a.carry_out_len + gridDim.x - 1) / gridDim.x;
         const uint32_t k0 = blockIdx.x * per;
         const uint32_t k1 = k0 + per < a.carry_out_len ? k0 + per : a.carry_out_len;
