@@ -53,6 +53,9 @@ namespace amps {
 #ifndef AMPS_FRONT_D3_BLOCKS
 #define AMPS_FRONT_D3_BLOCKS 3
 #endif
+#ifndef AMPS_FRONT_D1_BLOCKS
+#define AMPS_FRONT_D1_BLOCKS 4                 // depth 1: 125 registers as written; compiled for five (96 registers) the tile loop spills (round 6 probe, profiles/EXPERIMENTS.md)
+#endif
 constexpr int TILE = AMPS_TILE_SAMPLES;      // 512 samples per wave tile
 constexpr int HALO = AMPS_HALO_SAMPLES;      // 1024 = 2 tiles of history per chunk / push
 constexpr int CARRY_CAP = HALO + 64;         // samples kept per channel between pushes
@@ -395,7 +398,7 @@ __host__ __device__ __forceinline__ uint32_t exact_slice_word2(uint32_t SX, uint
 // raw samples are staged in the wave's LDS buffer and each lane slices 8 consecutive samples with one v_pk_mul, one
 // v_sub and one v_alignbit each -- the kernel is then bound by its HBM reads alone.
 template <int SPS, int DEPTH, bool BITS = false, bool TOL = false, int SL = AMPS_SLICER_ATAN_BOXCAR>
-__global__ __launch_bounds__(256, DEPTH == 1 ? 4 : DEPTH == 2 ? AMPS_FRONT_D2_BLOCKS : AMPS_FRONT_D3_BLOCKS) void recc_front_kernel(FrontArgs a)
+__global__ __launch_bounds__(256, DEPTH == 1 ? AMPS_FRONT_D1_BLOCKS : DEPTH == 2 ? AMPS_FRONT_D2_BLOCKS : AMPS_FRONT_D3_BLOCKS) void recc_front_kernel(FrontArgs a)
 {
     constexpr bool EXACT = SL == AMPS_SLICER_EXACT;
     constexpr bool PROD = SL == AMPS_SLICER_PRODUCT || EXACT;          // specs B and D stage the tile's raw samples in LDS
