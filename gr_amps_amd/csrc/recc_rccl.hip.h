@@ -385,7 +385,8 @@ inline int rccl_distribute(RcclState &r, const float2 *root_block, bool root_blo
     if (r.rank == root && root_block_on_host) {
         // a host block is staged into the receive buffer by a synchronous copy (the caller may reuse its memory on return; an async copy
         // from pageable memory gives no such guarantee) once the kernels of two pushes ago have read that buffer
-        if (r.used[slot] && hipEventSynchronize(r.freed[slot]) != hipSuccess) return broken("hipEventSynchronize", 0);
+        // (bounded: those kernels sit behind the collective that filled the buffer -- a peer that died inside it must not hang this rank here)
+        if (r.used[slot]) if (int e = rccl_wait_event(r, r.freed[slot])) return e;
         if (hipMemcpy(dst, root_block, sizeof(float2) * nsamp, hipMemcpyHostToDevice) != hipSuccess) return broken("hipMemcpy (staging)", 0);
         src = dst;                                               // in place
     } else {
