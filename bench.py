@@ -684,6 +684,15 @@ def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, w
                              "kernel": kname, "kernel_ms": round(kms, 4),
                              "note": "algorithmic flops of the same kernel (model in bench.py: chz_flops_per_frame / front_flops_per_sample) over the same in-run HIP-event duration"},
     }
+    # self-check of the in-run event timing against the host clock: the dominant kernel's events + the other kernels of a step (from the
+    # warmup steps) cannot exceed the step.  (Seen once in round 6: a sustained run right behind five rocprofv3 passes on the same box
+    # whose sampled events read 0.3185 ms inside a 0.3360 ms step with a 0.035 ms tail -- the step is the host clock's and stands.)
+    dom = "ms_channelizer" if wide else "ms_front"
+    tail_ms = sum(tm_all[k] / n_all for k in ("ms_front", "ms_resolve", "ms_decode", "ms_carry", "ms_channelizer") if k != dom)
+    step_ms = el_own / steps * 1e3
+    res["roofline"]["events_vs_step"] = {"kernel_ms_plus_other_kernels": round(kms + tail_ms, 4), "ms_per_step": round(step_ms, 4),
+                                         "consistent": bool(kms + tail_ms <= 1.02 * step_ms),
+                                         "kernel_ms_bound_from_step": round(step_ms - tail_ms, 4)}
     if power:
         res["power"] = power
     if identity is not None:
