@@ -670,6 +670,7 @@ int amps_recc_create(amps_recc_t **out, const amps_recc_cfg_t *cfg_in)
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { amps_recc_destroy(h); return -ENODEV; }
         h->max_waves = (uint32_t)prop.multiProcessorCount * 4u * (uint32_t)front_blocks_per_cu_for(h->sps, h->slicer, cfg->sync_tolerance != 0);   // exactly one resident round
+        if (const char *e = std::getenv("AMPS_RECC_MAX_WAVES")) { const long v = std::atol(e); if (v >= 4 && (uint32_t)v <= h->max_waves) h->max_waves = (uint32_t)v & ~3u; }   // experiments: fewer, longer wave streams (span geometry against the HBM channel interleave)
         {
             int nb = 0;
             hipError_t e;
