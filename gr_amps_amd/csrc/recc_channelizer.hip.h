@@ -100,7 +100,13 @@ typedef int chz_rsrc_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ chz_rsrc_t chz_make_rsrc(const void *base, uint64_t bytes)
 {
     const uint64_t a = (uint64_t)base;
+#ifdef CHZ_TIMING_NO_LOADS
+    // TIMING EXPERIMENT ONLY (profiles/r06/chz_no_loads.txt): every fast load falls outside the descriptor and returns zeros without touching
+    // memory -- WRONG results; what the kernel takes when its input stream costs nothing but the load instructions themselves
+    const uint32_t n = 64u; (void)bytes;
+#else
     const uint32_t n = bytes > 0xffffffffull ? 0xffffffffu : (uint32_t)bytes;
+#endif
     chz_rsrc_t r;
     r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
     r.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)((a >> 32) & 0xffffu));          // stride 0: a raw buffer, offsets and num_records in bytes
@@ -544,7 +550,13 @@ __device__ __forceinline__ void chz768_load1(cf2 (&ring)[4][CHZ768_R], const Chz
     if constexpr (FAST) {
         constexpr int CH = 3 * (4 * X + G) + K;                      // chunk of 256 samples behind the half-step's first sample
         const uint32_t voff = (uint32_t)t * (uint32_t)sizeof(float2);
+#ifdef CHZ_TIMING_CACHED_LOADS
+        // TIMING EXPERIMENT ONLY (profiles/r06/chz_no_loads.txt): every half-step reads the SAME 64 KB of its workgroup's range -- real (non-zero)
+        // data out of the L2, no HBM traffic; WRONG results
+        const uint32_t so = (soff & 0x7fffu) + 2048u * (uint32_t)(CH & ~1);
+#else
         const uint32_t so = soff + 2048u * (uint32_t)(CH & ~1);
+#endif
         // "+v": the new value is born in the ring's own register (see chz_load1_ring)
         if constexpr (CH & 1) asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen offset:2048" : "+v"(ring[J][SLOT]) : "v"(voff), "s"(rsrc), "s"(so));
         else asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(ring[J][SLOT]) : "v"(voff), "s"(rsrc), "s"(so));
