@@ -622,8 +622,10 @@ def run_workload(name, a, torch, dev, dist, rank, world, local, slicer, steps, w
         kname = "chz12_kernel<%d, slicer %s, D = %d>" % (a.taps, SLICERS[slicer], decim)
         flops = chz_flops_per_frame(a.taps, slicer, C) * (NW / float(decim))
         note = ("filter bank (fold + FFT-1024 = 4 x 16 x 16) + slicer spec %s in one kernel, %.1f flop per input byte: bound by VALU issue "
-                "and LDS exchange, not by HBM (both rooflines are reported; the HBM fraction is what the metric asks for).  Only slicer bits "
-                "(1/64 of the input) reach HBM; the bit-domain correlator (ms_front) and the decode kernels follow" % (SLICERS[slicer], flops / alg_bytes))
+                "and LDS exchange, not by HBM bandwidth (both rooflines are reported; the HBM fraction is what the metric asks for); in the sustained "
+                "stream the package sits on its 1.4 kW limit, and the ~180 W of reading the input from HBM cost the kernel 10 %% of its time in shader "
+                "clock, late loads another 5 %% (profiles/r06/chz_l2_touch.txt).  Only slicer bits (1/64 of the input) reach HBM; the trigger search "
+                "and the decode kernel follow" % (SLICERS[slicer], flops / alg_bytes))
     else:
         kms = tm["ms_front"] / max(1, tm["launches_front"])
         alg_bytes = ALG_BYTES_PER_SYMBOL_DIRECT * syms_per_step_rank
