@@ -62,3 +62,10 @@ def test_committed_bench_line_has_the_contract_fields():
     if tag >= "r02":
         assert line["roofline"]["traffic"] is None and "roofline_compute" in line
         assert abs(line["roofline_compute"]["frac"] - line["roofline_compute"]["achieved"] / 157.3) < 1e-3
+    if tag >= "r06":
+        # the line checks its own event timing against the host clock: the dominant kernel's events + the other kernels of a step fit the step
+        for part in (line, line.get("secondary") or line):
+            ev = part["roofline"]["events_vs_step"]
+            assert ev["consistent"] and ev["kernel_ms_plus_other_kernels"] <= 1.02 * ev["ms_per_step"], ev
+        r = line["roofline"]
+        assert abs(r["frac"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 8e12) < 2e-3
