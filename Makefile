@@ -4,7 +4,7 @@
 #
 #   make            library + host blocks + recctest + oracle
 #   make examples   examples/recc_abi_example (plain C99 against include/amps_recc.h)
-#   make check      the CPU test suite
+#   make check      the CPU test suite;  make check-gpu  the parity suite on an MI355X
 HIPCC   ?= /opt/rocm/bin/hipcc
 CXX     ?= g++
 CC      ?= gcc
@@ -42,4 +42,7 @@ clean:
 	rm -f $(PKG)/libamps_recc.so $(PKG)/libgnuradio-amps-mi355x.so $(PKG)/recctest examples/recc_abi_example
 	$(MAKE) -C oracle clean
 
-.PHONY: all examples check clean
+.PHONY: all examples check check-gpu clean
+
+check-gpu: all
+	python -m pytest tests -x -q -m gpu
